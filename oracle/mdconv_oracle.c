@@ -1,0 +1,79 @@
+/*
+ * mdconv_oracle.c -- CPU restatement (plain C + OpenMP) of the reference's hot path:
+ * DeformConv2d / ModulatedDeformConv2d / DeformConv3d / ModulatedDeformConv3d forward and
+ * backward.  TEST INFRASTRUCTURE ONLY -- see mdconv_oracle.h for who may load it and for the
+ * parity-pin statement (PARITY UNPINNED against reference-executed vectors).
+ *
+ * The arithmetic lives in mdconv_oracle_body.h, instantiated for float and double.
+ */
+#include "mdconv_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* src/config.h:18 -- EPS is FLT_EPSILON for every dtype */
+#define ORACLE_EPS 1.192092896e-07F
+
+/* GET_STEP = gcd by Euclid, src/config.h:43-60 */
+static int oracle_gcd(int batch, int step) {
+  int mx = batch > step ? batch : step;
+  int mn = batch > step ? step : batch;
+  while (mx % mn != 0) {
+    int t = mx % mn;
+    mx = mn;
+    mn = t;
+  }
+  return mn;
+}
+
+int oracle_out_size(const oracle_desc *d, int axis) {
+  return (d->in_sz[axis] + 2 * d->pad[axis] - (d->dil[axis] * (d->k_sz[axis] - 1) + 1)) /
+             d->stride[axis] + 1;
+}
+
+/* Shape checks of the host drivers (mdeformable_conv.cu:143-148) plus the ones the reference
+ * forgets (divisibility, positive in_step). */
+static int oracle_check(const oracle_desc *d, int *nd, int *modulated, int *osz) {
+  if (d->op < 0 || d->op > 3) return -1;
+  *nd = (d->op == ORACLE_DCN3D || d->op == ORACLE_MDCN3D) ? 3 : 2;
+  *modulated = (d->op == ORACLE_MDCN2D || d->op == ORACLE_MDCN3D);
+  if (d->batch <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->groups <= 0 || d->dgroups <= 0)
+    return -1;
+  if (d->in_step <= 0) return -1;
+  if (d->c_in % d->groups || d->c_out % d->groups || d->c_in % d->dgroups) return -1;
+  if (*nd == 2 && (d->in_sz[2] != 1 || d->k_sz[2] != 1 || d->stride[2] != 1 || d->pad[2] != 0 ||
+                   d->dil[2] != 1))
+    return -1;
+  for (int a = 0; a < 3; ++a) {
+    if (d->in_sz[a] <= 0 || d->k_sz[a] <= 0 || d->stride[a] <= 0 || d->dil[a] <= 0 ||
+        d->pad[a] < 0)
+      return -1;
+    osz[a] = oracle_out_size(d, a);
+    if (osz[a] <= 0) return -1;
+  }
+  return 0;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+#define REAL float
+#define FN(x) x##_f32
+#include "mdconv_oracle_body.h"
+#undef REAL
+#undef FN
+
+#define REAL double
+#define FN(x) x##_f64
+#include "mdconv_oracle_body.h"
+#undef REAL
+#undef FN

@@ -1,0 +1,89 @@
+"""Seeded synthetic workloads shared by the oracle tests, the golden fixtures and the GPU parity
+tests.  Input distributions follow SURVEY.md section 8d: input, offset, grad_output ~ N(0,1),
+mask = sigmoid(N(0,1)), weight ~ U(+-1/sqrt(C_in*K)) (reference reset_parameters,
+modulated_deform_conv.py:432-439), bias ~ 0.1*N(0,1).  Continuous offsets avoid quirk Q2.
+"""
+import math
+
+import torch
+
+import oracle
+
+D2, M2, D3, M3 = oracle.DCN2D, oracle.MDCN2D, oracle.DCN3D, oracle.MDCN3D
+
+
+def _c(name, op, B, C, O, in_sz, k, stride=1, padding=1, dilation=1, groups=1, dgroups=1,
+       in_step=64, bias=True, tier="small", seed=0, offset_scale=1.0):
+    return dict(name=name, op=op, B=B, C=C, O=O, in_sz=tuple(in_sz), k=k, stride=stride,
+                padding=padding, dilation=dilation, groups=groups, dgroups=dgroups,
+                in_step=in_step, bias=bias, tier=tier, seed=seed, offset_scale=offset_scale)
+
+
+CASES = [
+    # BASELINE.json configs[0] exactly: DeformConv2d 3x3, C_in=C_out=4, 8x8, B=1
+    _c("cfg1_dcn2d_c4_8x8_b1", D2, 1, 4, 4, (8, 8), 3, bias=False, seed=1),
+    # small sweeps: every op x stride / dilation / groups / deformable groups / bias / in_step
+    _c("dcn2d_s2_g2_dg2", D2, 2, 8, 6, (9, 7), 3, stride=2, groups=2, dgroups=2, in_step=1, seed=2),
+    _c("dcn2d_k1_dil1", D2, 3, 6, 5, (6, 6), 1, padding=0, in_step=2, bias=False, seed=3),
+    _c("dcn2d_dil2_dg4", D2, 2, 8, 8, (10, 9), 3, padding=2, dilation=2, dgroups=4, seed=4),
+    _c("mdcn2d_basic", M2, 2, 8, 8, (8, 8), 3, seed=5),
+    _c("mdcn2d_s2_g4_dg2", M2, 4, 8, 12, (11, 10), 3, stride=2, groups=4, dgroups=2, in_step=3, seed=6),
+    _c("mdcn2d_dil2_nobias", M2, 2, 6, 4, (9, 9), 3, padding=2, dilation=2, dgroups=3, bias=False, seed=7),
+    _c("mdcn2d_k2_asym", M2, 2, 4, 4, (7, 9), 2, padding=1, in_step=2, seed=8),
+    _c("mdcn2d_big_offsets", M2, 2, 4, 4, (8, 8), 3, seed=9, offset_scale=4.0),
+    _c("mdcn2d_rect_params", M2, 2, 4, 6, (9, 8), (3, 2), stride=(2, 1), padding=(1, 0), dilation=(1, 2), seed=10),
+    _c("dcn3d_basic", D3, 2, 4, 4, (5, 6, 4), 3, seed=11),
+    _c("dcn3d_s2_g2", D3, 2, 4, 6, (6, 5, 7), 3, stride=2, groups=2, dgroups=2, in_step=1, bias=False, seed=12),
+    _c("dcn3d_k2_dil2", D3, 1, 4, 4, (6, 6, 6), 2, padding=1, dilation=2, seed=13),
+    _c("mdcn3d_basic", M3, 2, 4, 4, (4, 6, 5), 3, seed=14),
+    _c("mdcn3d_dil2_dg2", M3, 2, 4, 8, (6, 7, 6), 3, padding=2, dilation=2, dgroups=2, in_step=1, seed=15),
+    _c("mdcn3d_g2_big_offsets", M3, 2, 8, 4, (5, 5, 5), 3, groups=2, dgroups=4, seed=16, offset_scale=3.0),
+    # medium: down-scaled analogues of BASELINE.json configs[1..4] (same K / stride / dilation /
+    # G : DG structure, channel counts that exercise the MFMA tiles incl. ragged edges)
+    _c("cfg2s_mdcn2d_c64_28x28_b4", M2, 4, 64, 64, (28, 28), 3, tier="medium", seed=21),
+    _c("cfg2s_mdcn2d_c48_o80_ragged", M2, 3, 48, 80, (19, 23), 3, in_step=1, tier="medium", seed=22),
+    _c("cfg2s_dcn2d_c64_28x28_b4", D2, 4, 64, 64, (28, 28), 3, tier="medium", seed=23),
+    _c("cfg3s_mdcn2d_g8_dg4", M2, 4, 64, 64, (20, 20), 3, groups=8, dgroups=4, tier="medium", seed=24),
+    _c("cfg4s_dcn3d_c16_12cubed_b2", D3, 2, 16, 16, (12, 12, 12), 3, tier="medium", seed=25),
+    _c("cfg5s_mdcn3d_c16_dil2", M3, 2, 16, 16, (6, 14, 14), 3, padding=2, dilation=2, tier="medium", seed=26),
+]
+
+CASE_BY_NAME = {c["name"]: c for c in CASES}
+
+
+def ndim(case):
+    return 3 if case["op"] in (D3, M3) else 2
+
+
+def _tup(v, nd):
+    return (v,) * nd if isinstance(v, int) else tuple(v)
+
+
+def out_size(case):
+    nd = ndim(case)
+    k, s, p, d = (_tup(case[x], nd) for x in ("k", "stride", "padding", "dilation"))
+    return tuple((case["in_sz"][a] + 2 * p[a] - (d[a] * (k[a] - 1) + 1)) // s[a] + 1 for a in range(nd))
+
+
+def make_inputs(case, dtype=torch.float32, device="cpu"):
+    """Deterministic inputs for a case (generated on CPU in fp64, then cast/moved)."""
+    g = torch.Generator().manual_seed(1000 + case["seed"])
+    nd = ndim(case)
+    k = _tup(case["k"], nd)
+    K = math.prod(k)
+    B, C, O = case["B"], case["C"], case["O"]
+    osz = out_size(case)
+    modulated = case["op"] in (M2, M3)
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+    t = {}
+    t["input"] = rn(B, C, *case["in_sz"])
+    t["offset"] = rn(B, case["dgroups"] * nd * K, *osz) * case["offset_scale"]
+    t["mask"] = torch.sigmoid(rn(B, case["dgroups"] * K, *osz)) if modulated else None
+    stdv = 1.0 / math.sqrt(C * K)
+    t["weight"] = (torch.rand(O, C // case["groups"], *k, generator=g, dtype=torch.float64) * 2 - 1) * stdv
+    t["bias"] = 0.1 * rn(O) if case["bias"] else None
+    t["grad_output"] = rn(B, O, *osz)
+    return {n: (None if v is None else v.to(dtype=dtype, device=device).contiguous()) for n, v in t.items()}
