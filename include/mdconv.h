@@ -1,0 +1,141 @@
+/*
+ * mdconv.h -- C ABI of the MI355X-native (gfx950) deformable-convolution library
+ * (libmdconv_hip.so).
+ *
+ * This is the drop-in boundary.  The reference's boundary is the CPython extension module
+ * `MDCONV_CUDA` (reference setup.py:37, imported at modulated_deform_conv.py:7) whose eight free
+ * functions take at::Tensor handles.  Each entry point below replaces exactly one of those
+ * eight; the tensor handles become plain device pointers, the shapes travel in `mdconv_desc`.
+ * The Python-side binding that re-creates the `MDCONV_CUDA` module on top of this ABI is
+ * modulated_deform_conv_amd/MDCONV_CUDA.py (ctypes); INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - All tensors are contiguous, row-major, on the current HIP device, in the layouts of the
+ *    reference:
+ *      input  [B, C_in, H, W(, L)]           weight [C_out, C_in/groups, kh, kw(, kl)]
+ *      bias   [C_out] (ignored when !with_bias)  output [B, C_out, Ho, Wo(, Lo)]
+ *      offset [B, DG*nd*K, Ho, Wo(, Lo)], channel = dg*nd*K + nd*tap + axis, axis order (h, w[, l])
+ *      mask   [B, DG*K,    Ho, Wo(, Lo)], channel = dg*K + tap,   tap = (i*kw + j)[*kl + k]
+ *  - `stream` is a hipStream_t (NULL = the null stream).  Calls are asynchronous on it.
+ *  - `workspace` is caller-owned device scratch of at least mdconv_workspace_bytes() bytes,
+ *    16-byte aligned; it may be NULL when that function returns 0.
+ *  - Backward entry points ACCUMULATE into every grad_* buffer, which is what the reference's
+ *    caller-allocated entry points do (deformable_conv.cu:327-333; the Python wrapper zero-fills,
+ *    modulated_deform_conv.py:53-56).  For the modulated-2D op, whose reference entry point
+ *    allocates zeros itself (mdeformable_conv.cu:404-411), the binding passes zeroed buffers.
+ *  - `in_step` is accepted for signature parity (reference README.md:30-31) and validated
+ *    (> 0); results never depend on it (the reference's own modulated-2D op is in_step-invariant).
+ *  - Return value: 0 on success, a negative MDCONV_E* code otherwise; mdconv_last_error() gives
+ *    the message for the calling thread.  Unlike the reference (which printf()s and swallows
+ *    launch errors, mdeformable_conv.cu:113-117) kernel launch failures are reported.
+ */
+#ifndef MDCONV_H_
+#define MDCONV_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDCONV_ABI_VERSION 1
+
+enum { MDCONV_F32 = 0, MDCONV_F16 = 1, MDCONV_F64 = 2 }; /* AT_DISPATCH_FLOATING_TYPES_AND_HALF */
+
+enum {
+  MDCONV_OK = 0,
+  MDCONV_EINVAL = -1,    /* bad descriptor / shape mismatch (reference: AT_ERROR -> RuntimeError) */
+  MDCONV_ENULL = -2,     /* a required pointer is NULL */
+  MDCONV_EWORKSPACE = -3,/* workspace too small / misaligned */
+  MDCONV_ELAUNCH = -4,   /* HIP launch or runtime error */
+  MDCONV_EUNSUPPORTED = -5
+};
+
+/* Kernel-path selector (tests and benchmarks): AUTO picks the MFMA implicit-GEMM kernels when
+ * the shape qualifies and the direct (VALU) kernels otherwise. */
+enum { MDCONV_PATH_AUTO = 0, MDCONV_PATH_DIRECT = 1, MDCONV_PATH_MFMA = 2 };
+
+typedef struct mdconv_desc {
+  int ndim;       /* 2 or 3 */
+  int modulated;  /* 0 = DeformConv (DCNv1), 1 = ModulatedDeformConv (DCNv2) */
+  int dtype;      /* MDCONV_F32 / F16 / F64 -- element type of every tensor */
+  int batch;      /* B */
+  int c_in;       /* C_in  */
+  int c_out;      /* C_out */
+  int in_sz[3];   /* H, W, L   (L = 1 when ndim == 2) */
+  int k_sz[3];    /* kh, kw, kl (kl = 1 when ndim == 2) */
+  int stride[3];  /* (…, 1)  */
+  int pad[3];     /* (…, 0)  */
+  int dil[3];     /* (…, 1)  */
+  int groups;     /* `group` of the reference signature */
+  int dgroups;    /* `deformable_group` */
+  int in_step;    /* accepted, validated > 0, otherwise unused */
+  int with_bias;
+} mdconv_desc;
+
+int mdconv_abi_version(void);
+const char *mdconv_last_error(void);
+
+/* Output extent on `axis`: (n + 2p - (d(k-1)+1))/s + 1   (mdeformable_conv.cu:150-153). */
+int mdconv_out_size(const mdconv_desc *d, int axis);
+
+/* Scratch bytes needed by the forward (backward = 0) or backward (backward = 1) of `d`. */
+size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward);
+
+/* Force a kernel path for subsequent calls of this process (MDCONV_PATH_*); returns the
+ * previous value.  The environment variable MDCONV_PATH=auto|direct|mfma sets the default. */
+int mdconv_set_path(int path);
+/* Path the last forward / backward call of this thread actually ran (MDCONV_PATH_DIRECT/MFMA). */
+int mdconv_last_path(void);
+
+/* --- replaces deform_conv2d_forward_cuda (deformable_conv.cu:117-123) ---------------------- */
+int mdconv_deform_conv2d_forward(const mdconv_desc *d, const void *input, const void *weight,
+                                 const void *bias, const void *offset, void *output,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+/* --- replaces deform_conv2d_backward_cuda (deformable_conv.cu:327-333) --------------------- */
+int mdconv_deform_conv2d_backward(const mdconv_desc *d, const void *input, const void *weight,
+                                  const void *bias, const void *offset, void *grad_input,
+                                  void *grad_weight, void *grad_bias, void *grad_offset,
+                                  const void *grad_output, void *workspace,
+                                  size_t workspace_bytes, void *stream);
+/* --- replaces modulated_deform_conv2d_forward_cuda (mdeformable_conv.cu:120-126) ----------- */
+int mdconv_modulated_deform_conv2d_forward(const mdconv_desc *d, const void *input,
+                                           const void *weight, const void *bias,
+                                           const void *offset, const void *mask, void *output,
+                                           void *workspace, size_t workspace_bytes, void *stream);
+/* --- replaces modulated_deform_conv2d_backward_cuda (mdeformable_conv.cu:361-366) ---------- */
+int mdconv_modulated_deform_conv2d_backward(const mdconv_desc *d, const void *input,
+                                            const void *weight, const void *bias,
+                                            const void *offset, const void *mask,
+                                            const void *grad_output, void *grad_input,
+                                            void *grad_offset, void *grad_mask, void *grad_weight,
+                                            void *grad_bias, void *workspace,
+                                            size_t workspace_bytes, void *stream);
+/* --- replaces deform_conv3d_forward_cuda (deformable_conv3d.cu:160-167) -------------------- */
+int mdconv_deform_conv3d_forward(const mdconv_desc *d, const void *input, const void *weight,
+                                 const void *bias, const void *offset, void *output,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+/* --- replaces deform_conv3d_backward_cuda (deformable_conv3d.cu:434-442) ------------------- */
+int mdconv_deform_conv3d_backward(const mdconv_desc *d, const void *input, const void *weight,
+                                  const void *bias, const void *offset, void *grad_input,
+                                  void *grad_weight, void *grad_bias, void *grad_offset,
+                                  const void *grad_output, void *workspace,
+                                  size_t workspace_bytes, void *stream);
+/* --- replaces modulated_deform_conv3d_forward_cuda (mdeformable_conv3d.cu:170-177) --------- */
+int mdconv_modulated_deform_conv3d_forward(const mdconv_desc *d, const void *input,
+                                           const void *weight, const void *bias,
+                                           const void *offset, const void *mask, void *output,
+                                           void *workspace, size_t workspace_bytes, void *stream);
+/* --- replaces modulated_deform_conv3d_backward_cuda (mdeformable_conv3d.cu:443-451) -------- */
+int mdconv_modulated_deform_conv3d_backward(const mdconv_desc *d, const void *input,
+                                            const void *weight, const void *bias,
+                                            const void *offset, const void *mask,
+                                            void *grad_input, void *grad_weight, void *grad_bias,
+                                            void *grad_offset, void *grad_mask,
+                                            const void *grad_output, void *workspace,
+                                            size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDCONV_H_ */

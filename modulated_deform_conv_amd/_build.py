@@ -1,0 +1,73 @@
+"""In-tree hipcc build of libmdconv_hip.so (gfx950 only).
+
+``python -m modulated_deform_conv_amd._build`` or ``__graft_entry__.build()``.  The .so stays
+next to this file (git-ignored, but it travels to the GPU box with the gpurun snapshot).
+"""
+import concurrent.futures
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libmdconv_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=fast",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build libmdconv_hip.so")
+    return exe
+
+
+def _deps():
+    return glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "mdconv.h")]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    if _stale(obj, [src] + _deps()):
+        cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        return obj, r.stderr
+    return obj, ""
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    if force:
+        for f in glob.glob(os.path.join(OBJ, "*.o")):
+            os.remove(f)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(_compile, srcs))
+    objs = [o for o, _ in results]
+    if verbose:
+        for _, log in results:
+            if log:
+                print(log, file=sys.stderr)
+    if force or _stale(LIB, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,74 @@
+"""ctypes loader for libmdconv_hip.so -- the C ABI declared in include/mdconv.h.
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing the product
+raises, loudly.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmdconv_hip.so")
+
+F32, F16, F64 = 0, 1, 2
+PATH_AUTO, PATH_DIRECT, PATH_MFMA = 0, 1, 2
+
+EXPORTS = (
+    "mdconv_abi_version", "mdconv_last_error", "mdconv_out_size", "mdconv_workspace_bytes",
+    "mdconv_set_path", "mdconv_last_path",
+    "mdconv_deform_conv2d_forward", "mdconv_deform_conv2d_backward",
+    "mdconv_modulated_deform_conv2d_forward", "mdconv_modulated_deform_conv2d_backward",
+    "mdconv_deform_conv3d_forward", "mdconv_deform_conv3d_backward",
+    "mdconv_modulated_deform_conv3d_forward", "mdconv_modulated_deform_conv3d_backward",
+)
+
+
+class MdconvDesc(ctypes.Structure):
+    """Mirror of ``struct mdconv_desc`` (include/mdconv.h)."""
+    _fields_ = [("ndim", ctypes.c_int), ("modulated", ctypes.c_int), ("dtype", ctypes.c_int),
+                ("batch", ctypes.c_int), ("c_in", ctypes.c_int), ("c_out", ctypes.c_int),
+                ("in_sz", ctypes.c_int * 3), ("k_sz", ctypes.c_int * 3),
+                ("stride", ctypes.c_int * 3), ("pad", ctypes.c_int * 3), ("dil", ctypes.c_int * 3),
+                ("groups", ctypes.c_int), ("dgroups", ctypes.c_int), ("in_step", ctypes.c_int),
+                ("with_bias", ctypes.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libmdconv_hip.so is not built (%s). Run `python -m modulated_deform_conv_amd._build` "
+                "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.mdconv_abi_version.restype = ctypes.c_int
+        L.mdconv_last_error.restype = ctypes.c_char_p
+        L.mdconv_out_size.restype = ctypes.c_int
+        L.mdconv_workspace_bytes.restype = ctypes.c_size_t
+        L.mdconv_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mdconv_set_path.restype = ctypes.c_int
+        L.mdconv_set_path.argtypes = [ctypes.c_int]
+        L.mdconv_last_path.restype = ctypes.c_int
+        for name in EXPORTS[6:]:
+            getattr(L, name).restype = ctypes.c_int
+        if L.mdconv_abi_version() != 1:
+            raise ImportError("libmdconv_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().mdconv_last_error().decode("utf-8", "replace")
+
+
+def set_path(path):
+    """Force the kernel path: 'auto' | 'direct' | 'mfma'.  Returns the previous setting."""
+    names = {"auto": PATH_AUTO, "direct": PATH_DIRECT, "mfma": PATH_MFMA}
+    prev = lib().mdconv_set_path(names[path] if isinstance(path, str) else int(path))
+    return {v: k for k, v in names.items()}[prev]
+
+
+def last_path():
+    return {0: "none", PATH_DIRECT: "direct", PATH_MFMA: "mfma"}[lib().mdconv_last_path()]

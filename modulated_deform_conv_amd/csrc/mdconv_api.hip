@@ -1,0 +1,338 @@
+// mdconv_api.hip -- the C ABI (include/mdconv.h): descriptor validation, path selection, and the
+// eight entry points that replace the reference's MDCONV_CUDA exports
+// (mdeformable_conv.cu:460-465 registers two; modulated_deform_conv.py calls all eight:
+//  :28, :57, :112, :142, :194, :225, :281, :313).
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mdconv_common.hpp"
+#include "mfma_kernels.hpp"
+
+namespace mdconv {
+
+static thread_local char g_err[512] = "";
+static thread_local int g_last_path = 0;
+static int g_path = -1;  // -1 = not initialised from the environment yet
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return MDCONV_ELAUNCH;
+  }
+  return MDCONV_OK;
+}
+
+static int current_path() {
+  if (g_path < 0) {
+    const char *e = getenv("MDCONV_PATH");
+    int p = MDCONV_PATH_AUTO;
+    if (e && !strcmp(e, "direct")) p = MDCONV_PATH_DIRECT;
+    if (e && !strcmp(e, "mfma")) p = MDCONV_PATH_MFMA;
+    g_path = p;
+  }
+  return g_path;
+}
+
+int fill_geom(const mdconv_desc *d, Geom *g) {
+  if (!d) {
+    set_error("descriptor is NULL");
+    return MDCONV_ENULL;
+  }
+  if (d->ndim != 2 && d->ndim != 3) {
+    set_error("ndim must be 2 or 3 (got %d)", d->ndim);
+    return MDCONV_EINVAL;
+  }
+  if (d->dtype != MDCONV_F32 && d->dtype != MDCONV_F16 && d->dtype != MDCONV_F64) {
+    set_error("unsupported dtype %d", d->dtype);
+    return MDCONV_EINVAL;
+  }
+  if (d->batch <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->groups <= 0 || d->dgroups <= 0) {
+    set_error("batch/channels/groups must be positive");
+    return MDCONV_EINVAL;
+  }
+  if (d->in_step <= 0) {  // the reference divides by it (config.h:43-60)
+    set_error("in_step must be positive (got %d)", d->in_step);
+    return MDCONV_EINVAL;
+  }
+  if (d->c_in % d->groups || d->c_out % d->groups) {
+    set_error("Input shape and kernel channels wont match: channels %d / %d not divisible by group %d",
+              d->c_in, d->c_out, d->groups);
+    return MDCONV_EINVAL;
+  }
+  if (d->c_in % d->dgroups) {
+    set_error("channels %d not divisible by deformable_group %d", d->c_in, d->dgroups);
+    return MDCONV_EINVAL;
+  }
+  memset(g, 0, sizeof(*g));
+  g->nd = d->ndim;
+  g->B = d->batch;
+  g->C = d->c_in;
+  g->O = d->c_out;
+  g->G = d->groups;
+  g->DG = d->dgroups;
+  int64_t S_i = 1, S_o = 1, K = 1;
+  for (int a = 0; a < 3; ++a) {
+    const bool used = a < d->ndim;
+    const int n = used ? d->in_sz[a] : 1, k = used ? d->k_sz[a] : 1, s = used ? d->stride[a] : 1;
+    const int p = used ? d->pad[a] : 0, dl = used ? d->dil[a] : 1;
+    if (n <= 0 || k <= 0 || s <= 0 || dl <= 0 || p < 0) {
+      set_error("bad size/kernel/stride/dilation/padding on axis %d", a);
+      return MDCONV_EINVAL;
+    }
+    const int o = (n + 2 * p - (dl * (k - 1) + 1)) / s + 1;
+    if (n + 2 * p - (dl * (k - 1) + 1) < 0 || o <= 0) {
+      set_error("empty output on axis %d", a);
+      return MDCONV_EINVAL;
+    }
+    g->in_sz[a] = n;
+    g->ksz[a] = k;
+    g->stride[a] = s;
+    g->pad[a] = p;
+    g->dil[a] = dl;
+    g->out_sz[a] = o;
+    S_i *= n;
+    S_o *= o;
+    K *= k;
+  }
+  const int64_t lim = 0x7fffffffLL;
+  if (S_i > lim || S_o * d->batch > lim || K > 4096 ||
+      (int64_t)d->batch * d->c_in * S_i > (int64_t)1 << 40) {
+    set_error("tensor too large for 32-bit pixel indexing");
+    return MDCONV_EUNSUPPORTED;
+  }
+  g->S_i = (int)S_i;
+  g->S_o = (int)S_o;
+  g->K = (int)K;
+  g->N = (int)(S_o * d->batch);
+  g->Cg = d->c_in / d->groups;
+  g->Og = d->c_out / d->groups;
+  g->Cdg = d->c_in / d->dgroups;
+  g->with_bias = d->with_bias ? 1 : 0;
+  g->modulated = d->modulated ? 1 : 0;
+  // gating flavours of the four reference files
+  const bool mdcn2d = d->ndim == 2 && d->modulated;
+  const bool dcn2d = d->ndim == 2 && !d->modulated;
+  g->load_eps = mdcn2d ? 0 : 1;
+  g->atom_eps = dcn2d ? 0 : 1;
+  g->range_gate = mdcn2d ? 1 : 0;
+  return MDCONV_OK;
+}
+
+static int require(const void *p, const char *name) {
+  if (!p) {
+    set_error("%s pointer is NULL", name);
+    return MDCONV_ENULL;
+  }
+  return MDCONV_OK;
+}
+
+static int check_ws(void *ws, size_t have, size_t need) {
+  if (need == 0) return MDCONV_OK;
+  if (!ws || have < need) {
+    set_error("workspace too small: need %zu bytes, have %zu", need, have);
+    return MDCONV_EWORKSPACE;
+  }
+  if (((uintptr_t)ws & 15) != 0) {
+    set_error("workspace must be 16-byte aligned");
+    return MDCONV_EWORKSPACE;
+  }
+  return MDCONV_OK;
+}
+
+static int run_forward(const mdconv_desc *d, int nd, int modulated, Tensors t, void *ws,
+                       size_t ws_bytes, void *stream) {
+  g_err[0] = 0;
+  Geom g;
+  int rc = fill_geom(d, &g);
+  if (rc) return rc;
+  if (d->ndim != nd || (d->modulated != 0) != (modulated != 0)) {
+    set_error("descriptor (ndim=%d, modulated=%d) does not match this entry point", d->ndim,
+              d->modulated);
+    return MDCONV_EINVAL;
+  }
+  if ((rc = require(t.input, "input")) || (rc = require(t.weight, "weight")) ||
+      (rc = require(t.offset, "offset")) || (rc = require(t.output, "output")))
+    return rc;
+  if (modulated && (rc = require(t.mask, "mask"))) return rc;
+  if (g.with_bias && (rc = require(t.bias, "bias"))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int path = current_path();
+  const bool mfma_ok = mfma_supported(g, d->dtype, false);
+  if (path == MDCONV_PATH_MFMA && !mfma_ok) {
+    set_error("MDCONV_PATH=mfma but this shape/dtype is not supported by the MFMA kernels");
+    return MDCONV_EUNSUPPORTED;
+  }
+  if (mfma_ok && path != MDCONV_PATH_DIRECT) {
+    if ((rc = check_ws(ws, ws_bytes, mfma_workspace_bytes(g, d->dtype, false)))) return rc;
+    g_last_path = MDCONV_PATH_MFMA;
+    return mfma_forward(g, d->dtype, t, ws, s);
+  }
+  g_last_path = MDCONV_PATH_DIRECT;
+  return direct_forward(g, d->dtype, t, s);
+}
+
+static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, void *ws,
+                        size_t ws_bytes, void *stream) {
+  g_err[0] = 0;
+  Geom g;
+  int rc = fill_geom(d, &g);
+  if (rc) return rc;
+  if (d->ndim != nd || (d->modulated != 0) != (modulated != 0)) {
+    set_error("descriptor (ndim=%d, modulated=%d) does not match this entry point", d->ndim,
+              d->modulated);
+    return MDCONV_EINVAL;
+  }
+  if ((rc = require(t.input, "input")) || (rc = require(t.weight, "weight")) ||
+      (rc = require(t.offset, "offset")) || (rc = require(t.grad_output, "grad_output")) ||
+      (rc = require(t.grad_input, "grad_input")) || (rc = require(t.grad_weight, "grad_weight")) ||
+      (rc = require(t.grad_offset, "grad_offset")))
+    return rc;
+  if (modulated && ((rc = require(t.mask, "mask")) || (rc = require(t.grad_mask, "grad_mask"))))
+    return rc;
+  if (g.with_bias && (rc = require(t.grad_bias, "grad_bias"))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int path = current_path();
+  const bool mfma_ok = mfma_supported(g, d->dtype, true);
+  if (path == MDCONV_PATH_MFMA && !mfma_ok) {
+    set_error("MDCONV_PATH=mfma but this shape/dtype is not supported by the MFMA kernels");
+    return MDCONV_EUNSUPPORTED;
+  }
+  if (mfma_ok && path != MDCONV_PATH_DIRECT) {
+    if ((rc = check_ws(ws, ws_bytes, mfma_workspace_bytes(g, d->dtype, true)))) return rc;
+    g_last_path = MDCONV_PATH_MFMA;
+    return mfma_backward(g, d->dtype, t, ws, s);
+  }
+  g_last_path = MDCONV_PATH_DIRECT;
+  return direct_backward(g, d->dtype, t, s);
+}
+
+}  // namespace mdconv
+
+using namespace mdconv;
+
+extern "C" {
+
+int mdconv_abi_version(void) { return MDCONV_ABI_VERSION; }
+const char *mdconv_last_error(void) { return g_err; }
+
+int mdconv_out_size(const mdconv_desc *d, int axis) {
+  if (!d || axis < 0 || axis > 2) return -1;
+  if (axis >= d->ndim) return 1;
+  return (d->in_sz[axis] + 2 * d->pad[axis] - (d->dil[axis] * (d->k_sz[axis] - 1) + 1)) /
+             d->stride[axis] + 1;
+}
+
+size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward) {
+  Geom g;
+  if (fill_geom(d, &g)) return 0;
+  if (current_path() == MDCONV_PATH_DIRECT) return 0;
+  if (!mfma_supported(g, d->dtype, backward != 0)) return 0;
+  return mfma_workspace_bytes(g, d->dtype, backward != 0);
+}
+
+int mdconv_set_path(int path) {
+  const int prev = current_path();
+  if (path >= MDCONV_PATH_AUTO && path <= MDCONV_PATH_MFMA) g_path = path;
+  return prev;
+}
+int mdconv_last_path(void) { return g_last_path; }
+
+int mdconv_deform_conv2d_forward(const mdconv_desc *d, const void *input, const void *weight,
+                                 const void *bias, const void *offset, void *output,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+  Tensors t = {};
+  t.input = input; t.weight = weight; t.bias = bias; t.offset = offset; t.output = output;
+  return run_forward(d, 2, 0, t, workspace, workspace_bytes, stream);
+}
+
+int mdconv_deform_conv2d_backward(const mdconv_desc *d, const void *input, const void *weight,
+                                  const void *bias, const void *offset, void *grad_input,
+                                  void *grad_weight, void *grad_bias, void *grad_offset,
+                                  const void *grad_output, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  Tensors t = {};
+  t.input = input; t.weight = weight; t.bias = bias; t.offset = offset;
+  t.grad_output = grad_output; t.grad_input = grad_input; t.grad_weight = grad_weight;
+  t.grad_bias = grad_bias; t.grad_offset = grad_offset;
+  return run_backward(d, 2, 0, t, workspace, workspace_bytes, stream);
+}
+
+int mdconv_modulated_deform_conv2d_forward(const mdconv_desc *d, const void *input,
+                                           const void *weight, const void *bias,
+                                           const void *offset, const void *mask, void *output,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+  Tensors t = {};
+  t.input = input; t.weight = weight; t.bias = bias; t.offset = offset; t.mask = mask;
+  t.output = output;
+  return run_forward(d, 2, 1, t, workspace, workspace_bytes, stream);
+}
+
+int mdconv_modulated_deform_conv2d_backward(const mdconv_desc *d, const void *input,
+                                            const void *weight, const void *bias,
+                                            const void *offset, const void *mask,
+                                            const void *grad_output, void *grad_input,
+                                            void *grad_offset, void *grad_mask, void *grad_weight,
+                                            void *grad_bias, void *workspace,
+                                            size_t workspace_bytes, void *stream) {
+  Tensors t = {};
+  t.input = input; t.weight = weight; t.bias = bias; t.offset = offset; t.mask = mask;
+  t.grad_output = grad_output; t.grad_input = grad_input; t.grad_weight = grad_weight;
+  t.grad_bias = grad_bias; t.grad_offset = grad_offset; t.grad_mask = grad_mask;
+  return run_backward(d, 2, 1, t, workspace, workspace_bytes, stream);
+}
+
+int mdconv_deform_conv3d_forward(const mdconv_desc *d, const void *input, const void *weight,
+                                 const void *bias, const void *offset, void *output,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+  Tensors t = {};
+  t.input = input; t.weight = weight; t.bias = bias; t.offset = offset; t.output = output;
+  return run_forward(d, 3, 0, t, workspace, workspace_bytes, stream);
+}
+
+int mdconv_deform_conv3d_backward(const mdconv_desc *d, const void *input, const void *weight,
+                                  const void *bias, const void *offset, void *grad_input,
+                                  void *grad_weight, void *grad_bias, void *grad_offset,
+                                  const void *grad_output, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  Tensors t = {};
+  t.input = input; t.weight = weight; t.bias = bias; t.offset = offset;
+  t.grad_output = grad_output; t.grad_input = grad_input; t.grad_weight = grad_weight;
+  t.grad_bias = grad_bias; t.grad_offset = grad_offset;
+  return run_backward(d, 3, 0, t, workspace, workspace_bytes, stream);
+}
+
+int mdconv_modulated_deform_conv3d_forward(const mdconv_desc *d, const void *input,
+                                           const void *weight, const void *bias,
+                                           const void *offset, const void *mask, void *output,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+  Tensors t = {};
+  t.input = input; t.weight = weight; t.bias = bias; t.offset = offset; t.mask = mask;
+  t.output = output;
+  return run_forward(d, 3, 1, t, workspace, workspace_bytes, stream);
+}
+
+int mdconv_modulated_deform_conv3d_backward(const mdconv_desc *d, const void *input,
+                                            const void *weight, const void *bias,
+                                            const void *offset, const void *mask,
+                                            void *grad_input, void *grad_weight, void *grad_bias,
+                                            void *grad_offset, void *grad_mask,
+                                            const void *grad_output, void *workspace,
+                                            size_t workspace_bytes, void *stream) {
+  Tensors t = {};
+  t.input = input; t.weight = weight; t.bias = bias; t.offset = offset; t.mask = mask;
+  t.grad_output = grad_output; t.grad_input = grad_input; t.grad_weight = grad_weight;
+  t.grad_bias = grad_bias; t.grad_offset = grad_offset; t.grad_mask = grad_mask;
+  return run_backward(d, 3, 1, t, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// mdconv_common.hpp -- shared host/device definitions for the gfx950 deformable-conv kernels.
+//
+// Sampling semantics restated from the reference:
+//   p_a   = o_a*stride_a - pad_a + tap_a*dil_a + delta_a            (mdeformable_conv.cu:78-79)
+//   low_a = floor(p_a), d_a = p_a - low_a; a corner contributes iff it lies inside the image
+//   (mdeformable_conv.cu:9-34, 256-267); validity is separable per axis, so it is folded into
+//   per-axis weights (an invalid side gets weight 0 and a clamped, always-in-bounds index).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/mdconv.h"
+
+namespace mdconv {
+
+#define MDCONV_EPS 1.192092896e-07F  // reference src/config.h:18
+
+// Device-side geometry (POD, passed by value as a kernel argument).
+struct Geom {
+  int nd, B, C, O, G, DG, K;
+  int in_sz[3], out_sz[3], ksz[3], stride[3], pad[3], dil[3];
+  int S_i, S_o;     // spatial volumes (input / output), < 2^31
+  int Cg, Og, Cdg;  // channels per conv group (in / out), channels per deformable group
+  int N;            // B * S_o, flattened output-pixel count, < 2^31
+  // backward gating flavours of the four reference files
+  int load_eps;    // high corners read only if d > EPS   (deformable_conv.cu:254-261, 3-D :336-338)
+  int atom_eps;    // high corners scattered only if d > EPS (mdeformable_conv.cu:285-293, 3-D)
+  int range_gate;  // grad_offset only when -1 < p < size   (mdeformable_conv.cu:295)
+  int with_bias;
+  int modulated;
+};
+
+template <typename T> struct Acc { using type = float; };
+template <> struct Acc<double> { using type = double; };
+
+__device__ __forceinline__ float ld(const float *p) { return *p; }
+__device__ __forceinline__ double ld(const double *p) { return *p; }
+__device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); }
+__device__ __forceinline__ void st(float *p, float v) { *p = v; }
+__device__ __forceinline__ void st(double *p, double v) { *p = v; }
+__device__ __forceinline__ void st(__half *p, float v) { *p = __float2half(v); }
+
+// Accumulating stores (the C ABI's backward entry points accumulate, include/mdconv.h).
+__device__ __forceinline__ void atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(double *p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(__half *p, float v) {
+  // 16-bit atomics do not exist as scalar ops: CAS on the containing aligned dword.
+  unsigned int *base = (unsigned int *)((uintptr_t)p & ~(uintptr_t)3);
+  const bool hi = ((uintptr_t)p & 2) != 0;
+  unsigned int old = *base, assumed;
+  do {
+    assumed = old;
+    unsigned short h = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
+    const float f = __half2float(__ushort_as_half(h)) + v;
+    const unsigned short nh = __half_as_ushort(__float2half(f));
+    const unsigned int repl = hi ? ((assumed & 0x0000ffffu) | ((unsigned int)nh << 16))
+                                 : ((assumed & 0xffff0000u) | nh);
+    old = atomicCAS(base, assumed, repl);
+  } while (old != assumed);
+}
+
+// Per-(tap, output pixel) sampling state, shared by every input channel of a deformable group.
+template <int ND, typename A> struct TapCoef {
+  A wl[ND];      // weight of the low side  (1-d), 0 if that side is outside the image
+  A wh[ND];      // weight of the high side (d),   0 if outside (or, backward, d <= EPS & load_eps)
+  A wha[ND];     // high-side weight used for the grad_input scatter (atom_eps flavour)
+  A sl[ND];      // d(val)/d(p_a) factor of the low side:  -1 or 0
+  A sh[ND];      // ... of the high side: +1 or 0
+  int base;      // element index (inside one [S_i] plane) of the clamped low corner
+  int delta[ND]; // index step low -> high per axis (0 when clamped)
+  bool inside;   // -1 < p_a < size_a on every axis
+};
+
+// Decompose a flattened output pixel index into per-axis coordinates.
+template <int ND> __device__ __forceinline__ void out_coords(const Geom &g, int pix, int *o) {
+  if (ND == 2) {
+    o[0] = pix / g.out_sz[1];
+    o[1] = pix - o[0] * g.out_sz[1];
+  } else {
+    const int wl = g.out_sz[1] * g.out_sz[2];
+    o[0] = pix / wl;
+    const int r = pix - o[0] * wl;
+    o[1] = r / g.out_sz[2];
+    o[2] = r - o[1] * g.out_sz[2];
+  }
+}
+
+template <int ND> __device__ __forceinline__ void tap_coords(const Geom &g, int tap, int *t) {
+  if (ND == 2) {
+    t[0] = tap / g.ksz[1];
+    t[1] = tap - t[0] * g.ksz[1];
+  } else {
+    const int wl = g.ksz[1] * g.ksz[2];
+    t[0] = tap / wl;
+    const int r = tap - t[0] * wl;
+    t[1] = r / g.ksz[2];
+    t[2] = r - t[1] * g.ksz[2];
+  }
+}
+
+// Build the sampling state from the ND offsets of one (tap, pixel).  `bwd` selects the
+// backward gating flavours.
+template <int ND, typename A>
+__device__ __forceinline__ void make_tap(const Geom &g, const int *o, const int *t,
+                                         const A *delta, bool bwd, TapCoef<ND, A> &tc) {
+  int idx = 0;
+  bool inside = true;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    const int size = g.in_sz[a];
+    const A p = (A)(o[a] * g.stride[a] - g.pad[a] + t[a] * g.dil[a]) + delta[a];
+    inside = inside && (p > (A)-1) && (p < (A)size);
+    // clamp before the int conversion so wild offsets cannot overflow
+    const A pc = p < (A)-2 ? (A)-2 : (p > (A)(size + 1) ? (A)(size + 1) : p);
+    const A fl = floor(pc);
+    const int low = (int)fl;
+    const A d = pc - fl;
+    const bool vl = (low >= 0) && (low <= size - 1);
+    const bool vh = (low + 1 >= 0) && (low + 1 <= size - 1);
+    const bool big = d > (A)MDCONV_EPS;
+    const bool vh_load = vh && (!bwd || !g.load_eps || big);
+    const bool vh_atom = vh && (!g.atom_eps || big);
+    tc.wl[a] = vl ? (A)1 - d : (A)0;
+    tc.wh[a] = vh_load ? d : (A)0;
+    tc.wha[a] = vh_atom ? d : (A)0;
+    tc.sl[a] = vl ? (A)-1 : (A)0;
+    tc.sh[a] = vh_load ? (A)1 : (A)0;
+    const int lc = low < 0 ? 0 : (low > size - 1 ? size - 1 : low);
+    const int hc = low + 1 < 0 ? 0 : (low + 1 > size - 1 ? size - 1 : low + 1);
+    int plane_stride = 1;
+#pragma unroll
+    for (int a2 = a + 1; a2 < ND; ++a2) plane_stride *= g.in_sz[a2];
+    idx += lc * plane_stride;
+    tc.delta[a] = (hc - lc) * plane_stride;
+  }
+  tc.base = idx;
+  tc.inside = inside;
+}
+
+// Corner ci: bit (ND-1-a) set <=> axis a takes the high side (the reference's v1..v4 / v1..v8
+// order, deformable_conv3d.cu:21-44).
+template <int ND, typename A>
+__device__ __forceinline__ int corner_index(const TapCoef<ND, A> &tc, int ci) {
+  int idx = tc.base;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) idx += ((ci >> (ND - 1 - a)) & 1) ? tc.delta[a] : 0;
+  return idx;
+}
+template <int ND, typename A>
+__device__ __forceinline__ A corner_weight(const TapCoef<ND, A> &tc, int ci) {
+  A w = (A)1;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) w *= ((ci >> (ND - 1 - a)) & 1) ? tc.wh[a] : tc.wl[a];
+  return w;
+}
+template <int ND, typename A>
+__device__ __forceinline__ A corner_weight_atom(const TapCoef<ND, A> &tc, int ci) {
+  A w = (A)1;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) w *= ((ci >> (ND - 1 - a)) & 1) ? tc.wha[a] : tc.wl[a];
+  return w;
+}
+// d(val)/d(p_axis) coefficient of corner ci.
+template <int ND, typename A>
+__device__ __forceinline__ A corner_dweight(const TapCoef<ND, A> &tc, int ci, int axis) {
+  A w = (A)1;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    const bool hi = (ci >> (ND - 1 - a)) & 1;
+    w *= (a == axis) ? (hi ? tc.sh[a] : tc.sl[a]) : (hi ? tc.wh[a] : tc.wl[a]);
+  }
+  return w;
+}
+
+// ---- host-side helpers ------------------------------------------------------------------------
+int fill_geom(const mdconv_desc *d, Geom *g);  // validates; returns MDCONV_* code
+void set_error(const char *fmt, ...);
+int check_launch(const char *what);
+
+struct Tensors {
+  const void *input, *weight, *bias, *offset, *mask, *grad_output;
+  void *output, *grad_input, *grad_weight, *grad_bias, *grad_offset, *grad_mask;
+};
+
+// direct (VALU) path, any shape / dtype
+int direct_forward(const Geom &g, int dtype, const Tensors &t, hipStream_t stream);
+int direct_backward(const Geom &g, int dtype, const Tensors &t, hipStream_t stream);
+
+}  // namespace mdconv

@@ -1,0 +1,12 @@
+// mfma_kernels.hpp -- entry points of the MFMA implicit-GEMM path (see mfma_*.hip).
+#pragma once
+#include "mdconv_common.hpp"
+
+namespace mdconv {
+
+bool mfma_supported(const Geom &g, int dtype, bool backward);
+size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward);
+int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
+int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
+
+}  // namespace mdconv

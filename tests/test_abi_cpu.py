@@ -1,0 +1,108 @@
+"""CPU-side checks of the drop-in boundary (no GPU, no compute calls):
+the C-ABI library loads, exports every symbol include/mdconv.h declares, validates descriptors,
+and the Python surface mirrors the reference's names / signatures / error behaviour."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from modulated_deform_conv_amd import _build, _capi
+    _build.build()
+    return _capi
+
+
+def test_library_exports_every_declared_symbol(capi):
+    hdr = open(os.path.join(ROOT, "include", "mdconv.h")).read()
+    declared = set(re.findall(r"\b(mdconv_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) == 14 and declared == set(capi.EXPORTS)
+    L = capi.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.mdconv_abi_version() == 1
+
+
+def test_desc_struct_matches_header(capi):
+    hdr = open(os.path.join(ROOT, "include", "mdconv.h")).read()
+    body = hdr[hdr.index("typedef struct mdconv_desc {"):hdr.index("} mdconv_desc;")]
+    fields = re.findall(r"^\s*int\s+([a-z_]+)(?:\[3\])?;", body, re.M)
+    assert fields == [f[0] for f in capi.MdconvDesc._fields_]
+
+
+def _desc(capi, **kw):
+    d = capi.MdconvDesc()
+    d.ndim, d.modulated, d.dtype, d.batch, d.c_in, d.c_out = 2, 1, 0, 2, 8, 8
+    d.in_sz = (ctypes.c_int * 3)(8, 8, 1)
+    d.k_sz = (ctypes.c_int * 3)(3, 3, 1)
+    d.stride = (ctypes.c_int * 3)(1, 1, 1)
+    d.pad = (ctypes.c_int * 3)(1, 1, 0)
+    d.dil = (ctypes.c_int * 3)(1, 1, 1)
+    d.groups, d.dgroups, d.in_step, d.with_bias = 1, 1, 64, 0
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_descriptor_validation_without_gpu(capi):
+    L = capi.lib()
+    null = ctypes.c_void_p(0)
+
+    def fwd(d):
+        return L.mdconv_modulated_deform_conv2d_forward(ctypes.byref(d), null, null, null, null,
+                                                        null, null, null, ctypes.c_size_t(0), null)
+    assert fwd(_desc(capi, ndim=4)) == -1 and "ndim" in capi.last_error()
+    assert fwd(_desc(capi, in_step=0)) == -1 and "in_step" in capi.last_error()
+    assert fwd(_desc(capi, groups=3)) == -1 and "wont match" in capi.last_error()
+    assert fwd(_desc(capi, dgroups=3)) == -1
+    assert fwd(_desc(capi, dtype=7)) == -1
+    assert fwd(_desc(capi)) == -2 and "NULL" in capi.last_error()          # pointers missing
+    d3 = _desc(capi)
+    assert L.mdconv_deform_conv3d_forward(ctypes.byref(d3), null, null, null, null, null, null,
+                                          ctypes.c_size_t(0), null) == -1   # wrong entry point
+    assert L.mdconv_out_size(ctypes.byref(_desc(capi)), 0) == 8
+    big = _desc(capi)
+    big.in_sz = (ctypes.c_int * 3)(56, 56, 1)
+    big.stride = (ctypes.c_int * 3)(2, 2, 1)
+    assert L.mdconv_out_size(ctypes.byref(big), 1) == 28
+
+
+def test_extension_module_surface_matches_reference():
+    """The 8 positional signatures of SURVEY.md section 8b."""
+    from modulated_deform_conv_amd import MDCONV_CUDA as M
+    expect = {
+        "deform_conv2d_forward_cuda": 17, "deform_conv2d_backward_cuda": 21,
+        "modulated_deform_conv2d_forward_cuda": 17, "modulated_deform_conv2d_backward_cuda": 18,
+        "deform_conv3d_forward_cuda": 21, "deform_conv3d_backward_cuda": 25,
+        "modulated_deform_conv3d_forward_cuda": 22, "modulated_deform_conv3d_backward_cuda": 27,
+    }
+    for name, nargs in expect.items():
+        assert len(inspect.signature(getattr(M, name)).parameters) == nargs, name
+
+
+def test_python_surface_and_cpu_behaviour():
+    from modulated_deform_conv_amd import modulated_deform_conv as mdc
+    m = mdc.ModulatedDeformConv2d(8, 4, 3, padding=1, groups=2, deformable_groups=2)
+    assert m.weight.shape == (4, 4, 3, 3) and m.bias is None and m.with_bias is False
+    assert abs(m.weight.abs().max().item()) <= 1 / (8 * 9) ** 0.5
+    m3 = mdc.DeformConv3d(4, 6, (3, 2, 1), bias=True)
+    assert m3.weight.shape == (6, 4, 3, 2, 1) and torch.equal(m3.bias.data, torch.zeros(6))
+    p = mdc.ModulatedDeformConv2dPack(4, 4, 3, padding=1, deformable_groups=2)
+    assert set(p.state_dict()) == {"weight", "conv_offset.weight", "conv_offset.bias",
+                                   "conv_mask.weight", "conv_mask.bias"}
+    assert p.conv_offset.out_channels == 2 * 2 * 9 and p.conv_mask.out_channels == 2 * 9
+    with pytest.raises(AssertionError):
+        mdc.DeformConv2d(5, 4, 3, groups=2)
+    # CPU tensors: NotImplementedError, exactly like the reference (no CPU fallback in the product)
+    x = torch.randn(1, 8, 5, 5)
+    with pytest.raises(NotImplementedError):
+        m(x, torch.zeros(1, 2 * 18, 5, 5), torch.ones(1, 2 * 9, 5, 5))
+    assert mdc.DeformConv2dFunction._infer_shape(
+        type("C", (), dict(stride=(2, 2), padding=(1, 1), dilation=(1, 1)))(), torch.empty(2, 4, 9, 7),
+        torch.empty(6, 4, 3, 3)) == (2, 6, 5, 4)

@@ -1,0 +1,89 @@
+"""GPU tests of the autograd Functions / nn.Modules (the reference's L2/L3 surface) including the
+my_test.py scenario (reference my_test.py:1-35, known answers in SURVEY.md section 4)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.cases import CASE_BY_NAME, make_inputs
+from tests.util import assert_close, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_my_test_scenario_on_device():
+    from modulated_deform_conv_amd.modulated_deform_conv import deform_conv2d, modulated_deform_conv2d
+    counts = torch.tensor([[4, 6, 6, 6, 4], [6, 9, 9, 9, 6], [6, 9, 9, 9, 6], [6, 9, 9, 9, 6],
+                           [4, 6, 6, 6, 4]], dtype=torch.float32, device="cuda")
+    for fn, modulated in ((deform_conv2d, False), (modulated_deform_conv2d, True)):
+        data = torch.ones(1, 1, 5, 5, device="cuda", requires_grad=True)
+        offset = torch.zeros(1, 18, 5, 5, device="cuda", requires_grad=True)
+        mask = torch.ones(1, 9, 5, 5, device="cuda", requires_grad=True)
+        weight = torch.ones(1, 1, 3, 3, device="cuda", requires_grad=True)
+        bias = torch.zeros(1, device="cuda", requires_grad=True)
+        args = (weight, bias, 1, 1, 1, 1, 1, 64)
+        out = fn(data, offset, mask, *args) if modulated else fn(data, offset, *args)
+        assert torch.equal(out[0, 0], counts) and out.sum().item() == 169
+        out.sum().backward()
+        assert torch.equal(data.grad[0, 0], counts)
+        assert torch.equal(weight.grad.flatten(),
+                           torch.tensor([16., 20, 16, 20, 25, 20, 16, 20, 16], device="cuda"))
+        assert bias.grad.item() == 25
+        if modulated:
+            gm0 = torch.zeros(5, 5, device="cuda")
+            gm0[1:, 1:] = 1
+            assert torch.equal(mask.grad[0, 0], gm0)
+            assert offset.grad.abs().sum().item() == 52      # quirk Q2, modulated-2D flavour
+
+
+@pytest.mark.parametrize("name", ["mdcn2d_s2_g4_dg2", "dcn2d_dil2_dg4", "dcn3d_basic", "mdcn3d_dil2_dg2"])
+def test_module_forward_backward_matches_oracle(name):
+    from modulated_deform_conv_amd import modulated_deform_conv as mdc
+    case = CASE_BY_NAME[name]
+    t = make_inputs(case, dtype=torch.float32, device="cuda")
+    cls = {0: mdc.DeformConv2d, 1: mdc.ModulatedDeformConv2d, 2: mdc.DeformConv3d,
+           3: mdc.ModulatedDeformConv3d}[case["op"]]
+    mod = cls(case["C"], case["O"], case["k"], case["stride"], case["padding"], case["dilation"],
+              case["groups"], case["dgroups"], bias=case["bias"], in_step=case["in_step"]).cuda()
+    with torch.no_grad():
+        mod.weight.copy_(t["weight"])
+        if case["bias"]:
+            mod.bias.copy_(t["bias"])
+    x = t["input"].clone().requires_grad_()
+    off = t["offset"].clone().requires_grad_()
+    ins = [x, off]
+    if t["mask"] is not None:
+        ins.append(t["mask"].clone().requires_grad_())
+    out = mod(*ins)
+    out.backward(t["grad_output"])
+    want_out, want = run_oracle(case, t, torch.float32)
+    assert_close("output", out, want_out, 1e-4)
+    assert_close("grad_input", x.grad, want["grad_input"], 1e-4)
+    assert_close("grad_offset", off.grad, want["grad_offset"], 1e-4)
+    assert_close("grad_weight", mod.weight.grad, want["grad_weight"], 1e-4)
+    if t["mask"] is not None:
+        assert_close("grad_mask", ins[2].grad, want["grad_mask"], 1e-4)
+    if case["bias"]:
+        assert_close("grad_bias", mod.bias.grad, want["grad_bias"], 1e-4)
+
+
+def test_zero_offset_equals_conv2d_on_device():
+    from modulated_deform_conv_amd.modulated_deform_conv import modulated_deform_conv2d
+    torch.manual_seed(0)
+    x = torch.randn(2, 16, 14, 14, device="cuda", requires_grad=True)
+    w = torch.randn(32, 16, 3, 3, device="cuda", requires_grad=True)
+    off = torch.zeros(2, 18, 14, 14, device="cuda")
+    m = torch.ones(2, 9, 14, 14, device="cuda")
+    out = modulated_deform_conv2d(x, off, m, w, None, 1, 1, 1, 1, 1, 64)
+    ref = F.conv2d(x, w, None, 1, 1)
+    assert_close("conv2d", out, ref, 1e-4)
+
+
+def test_pack_module_runs():
+    from modulated_deform_conv_amd import modulated_deform_conv as mdc
+    torch.manual_seed(0)
+    m = mdc.ModulatedDeformConv2dPack(8, 8, 3, padding=1, deformable_groups=2, bias=True).cuda()
+    x = torch.randn(2, 8, 10, 10, device="cuda", requires_grad=True)
+    y = m(x)
+    y.square().mean().backward()
+    assert y.shape == (2, 8, 10, 10) and torch.isfinite(x.grad).all()
+    assert m.conv_offset.weight.grad is not None and m.conv_mask.weight.grad is not None

@@ -1,0 +1,91 @@
+"""GPU parity tests (``-m gpu``): the HIP path, called through the MDCONV_CUDA surface (ctypes ->
+C ABI -> kernels), against the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star: "within 1e-4 fp32"), read relative to scale as SURVEY.md
+section 8c prescribes:  max|got - want| <= 1e-4 * max(1, max|want|)   for fp32,
+1e-10 for fp64, and 2e-2 for fp16 storage (fp32 arithmetic inside; compared with the fp32 oracle
+run on the fp16-rounded inputs).
+"""
+import pytest
+import torch
+
+from tests.cases import CASES, make_inputs
+from tests.util import assert_close, run_oracle, run_product
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.float64: 1e-10, torch.float16: 2e-2}
+
+
+def _check(case, dtype, path):
+    t = make_inputs(case, dtype=dtype, device="cuda")
+    out, grads, paths = run_product(case, t, path)
+    torch.cuda.synchronize()
+    odt = torch.float64 if dtype == torch.float64 else torch.float32
+    want_out, want = run_oracle(case, t, odt)
+    tol = TOL[dtype]
+    assert_close("output", out, want_out, tol)
+    for key, g in grads.items():
+        if want[key] is None:
+            continue
+        assert_close(key, g, want[key], tol)
+    return paths
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_fp32_direct_path(case):
+    assert _check(case, torch.float32, "direct") == ["direct", "direct"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_fp32_auto_path(case):
+    _check(case, torch.float32, "auto")
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["tier"] == "small"], ids=lambda c: c["name"])
+def test_fp64(case):
+    _check(case, torch.float64, "auto")
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["tier"] == "small"][::2] +
+                         [c for c in CASES if c["tier"] == "medium"][:2], ids=lambda c: c["name"])
+def test_fp16(case):
+    _check(case, torch.float16, "auto")
+
+
+def test_accumulate_semantics():
+    """Backward entry points accumulate into caller buffers (deformable_conv.cu:327-333)."""
+    from tests.cases import CASE_BY_NAME
+    case = CASE_BY_NAME["dcn2d_s2_g2_dg2"]
+    t = make_inputs(case, dtype=torch.float32, device="cuda")
+    _, g1, _ = run_product(case, t, "auto")
+    from modulated_deform_conv_amd import MDCONV_CUDA as M
+    gi, gw = torch.ones_like(t["input"]), torch.ones_like(t["weight"])
+    gb, goff = torch.ones_like(t["bias"]), torch.ones_like(t["offset"])
+    M.deform_conv2d_backward_cuda(t["input"], t["weight"], t["bias"], t["offset"], gi, gw, gb, goff,
+                                  t["grad_output"], 3, 3, 2, 2, 1, 1, 1, 1, 2, 2, 1, True)
+    for got, base in ((gi, g1["grad_input"]), (gw, g1["grad_weight"]), (gb, g1["grad_bias"]),
+                      (goff, g1["grad_offset"])):
+        assert_close("accumulate", got - 1, base, 1e-4)
+
+
+def test_error_behaviour_on_device():
+    from modulated_deform_conv_amd import MDCONV_CUDA as M
+    x = torch.randn(2, 4, 6, 6, device="cuda")
+    w = torch.randn(4, 4, 3, 3, device="cuda")
+    off = torch.zeros(2, 18, 6, 6, device="cuda")
+    m = torch.ones(2, 9, 6, 6, device="cuda")
+    b = x.new_empty(0)
+    geo = (3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 64, False)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        M.modulated_deform_conv2d_forward_cuda(x.transpose(2, 3), w, b, off, m, *geo)
+    with pytest.raises(RuntimeError, match="kernel shape"):
+        M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, 5, 5, *geo[2:])
+    with pytest.raises(RuntimeError, match="channels"):
+        M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo[:8], 2, 1, 64, False)
+    with pytest.raises(RuntimeError, match="offset shape"):
+        M.modulated_deform_conv2d_forward_cuda(x, w, b, off[:, :10], m, *geo)
+    with pytest.raises(RuntimeError, match="in_step"):
+        M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo[:10], 0, False)
+    out = M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo)
+    assert out.shape == (2, 4, 6, 6)
