@@ -48,6 +48,24 @@ def _compile(src):
     return obj, ""
 
 
+def build_variant(name, extra_flags):
+    """Developer aid: build csrc with extra -D flags into libmdconv_hip_<name>.so (load it with
+    MDCONV_LIB=<path>).  Used for ablation experiments only."""
+    obj_dir = os.path.join(CSRC, "_obj_" + name)
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = []
+    for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        r = subprocess.run([_hipcc()] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr)
+        objs.append(obj)
+    lib = os.path.join(HERE, "libmdconv_hip_%s.so" % name)
+    subprocess.run([_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs, check=True)
+    return lib
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmdconv_hip.so")
+LIB_PATH = os.environ.get("MDCONV_LIB") or os.path.join(HERE, "libmdconv_hip.so")
 
 F32, F16, F64 = 0, 1, 2
 PATH_AUTO, PATH_DIRECT, PATH_MFMA = 0, 1, 2

@@ -1,0 +1,281 @@
+// mfma_fwd.hip -- forward as ONE fused implicit GEMM on the gfx950 matrix cores (fp32).
+//
+//   out[o, n] = sum_{tap, c} W[o, c, tap] * ( mask[tap, n] * interp(input[c], p(tap, n)) )
+//
+// M = output channels, N = flattened output pixels (b, pix), K = (tap, c), tap-major.
+// The column operand (the reference's [C*K, step*S_o] `columns` buffer, 925 MB at cfg2,
+// mdeformable_conv.cu:159) is never written to HBM: each workgroup gathers a BK x BN slab of it
+// straight into LDS and feeds v_mfma_f32_32x32x2_f32 (exact fp32, MI355X_MICROARCH.md).
+//
+// Design rule learned on the hardware (tools/ubench_mfma2.hip): the f32 MFMA executes on the
+// SIMD's vector-FMA datapath, so a VALU instruction of ANY co-resident wave steals ~3.5 cycles
+// from the matrix pipe (NV=128 VALU per 16 MFMAs: 155 -> 108 TFLOP/s even at 4 waves/SIMD).
+// The kernel is therefore built to issue almost no VALU work in the K loop:
+//   * every thread owns ONE output pixel for the whole kernel; per (tap, deformable group) it
+//     builds the sampling state ONCE: 2^ND corner byte-offsets (image / channel-subset base
+//     folded in) and 2^ND corner weights (validity and the mask folded in) -- offset/mask are
+//     read K times per tile, not C*K times;
+//   * gathers are raw buffer loads `buffer_load_dword v, voff[corner], rsrc(input), soffset`:
+//     the per-chunk channel base lives in the SGPR soffset, so a gather costs zero VALU;
+//   * the weight operand is pre-packed in MFMA-fragment order (mfma_tile.hpp) and fetched with
+//     buffer_load_dwordx4 (lane-constant voffset, chunk base in soffset, fragment index in the
+//     immediate): zero VALU, never touches LDS;
+//   * interpolation = 2^ND FMAs per sample; the B slab is written to a double-buffered k-major
+//     LDS tile (n across lanes, conflict-free) at lane-constant addresses;
+//   * the chunk loop is unrolled by two (LDS buffer parity and the A-fragment register set are
+//     compile-time), one barrier per chunk, requests for chunk t+1 are issued before the MFMAs
+//     of chunk t.
+// B fragments are read with ds_read_b32: lanes 0-31 / 32-63 hit two different k rows, each 32
+// consecutive dwords -> no bank conflicts.
+#include "mfma_kernels.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "mfma_tile.hpp"
+
+namespace mdconv {
+
+namespace {
+
+template <int ND, bool MOD, int BM, int BN, int WM, int WN, bool PADK>
+__global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
+                                                       const float *__restrict__ input,
+                                                       const float *__restrict__ wp,
+                                                       const float *__restrict__ bias,
+                                                       const float *__restrict__ offset,
+                                                       const float *__restrict__ mask,
+                                                       float *__restrict__ output, int ntm, int ntn) {
+  constexpr int BK = kBK;
+  constexpr int NC = 1 << ND;
+  constexpr int MB = WM / 32, NB = WN / 32;   // 32x32 MFMA blocks per wave
+  constexpr int WAVES_N = BN / WN;
+  constexpr int KSUBS = 256 / BN;             // k-subsets of the B-slab generation
+  constexpr int CPT = BK / KSUBS;             // channels per thread per chunk
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  static_assert(BK == 16 && CPT >= 1 && BN <= 256 && MB * 2 * 1024 <= 4096, "tile shape");
+
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BK * BN];  // [2][BK][BN]
+
+  // ---- tile assignment (XCD-aware: consecutive tiles -> same XCD L2) ----
+  const int grp = blockIdx.y;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tn = tile / ntm, tm = tile - tn * ntm;
+  const int o0 = tm * BM;
+  const int n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int kh = lane >> 5;
+
+  // ---- this thread's output pixel for the gather ----
+  const int j = tid % BN, ksub = tid / BN;
+  const int n_g = min(n0 + j, g.N - 1);
+  const int b_g = n_g / g.S_o;
+  const int pix_g = n_g - b_g * g.S_o;
+  int oc[ND];
+  out_coords<ND>(g, pix_g, oc);
+
+  const int cchunks = pd.Cgp / BK;
+  const int T = g.K * cchunks;
+  const int mblks = pd.Ogp / 32;
+  const int slab_bytes = mblks * 2 * 64 * 4 * 4;   // one chunk of packed weights
+
+  // buffer resources (wave-uniform: built from kernel arguments and blockIdx only)
+  const rsrc_t r_in = make_rsrc(input, (size_t)g.B * g.C * g.S_i * sizeof(float));
+  const rsrc_t r_wp = make_rsrc(wp + (size_t)grp * T * (slab_bytes / 4), (size_t)T * slab_bytes);
+  const int a_voff = (((o0 + wm0) / 32) * 2 * 64 + lane) * 16;   // bytes, lane-constant
+  // byte offset of (image b_g, first channel of this thread's k-subset); the chunk's channel
+  // base is added through the scalar offset
+  const int img_voff = (b_g * g.C + grp * g.Cg + ksub * CPT) * g.S_i * 4;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+  int voff[NC];     // corner byte offsets for the current (tap, dg)
+  float wgt[NC];    // corner weights * mask
+  float rg[CPT][NC];
+  int cur_tap = -1, cur_dg = -1;
+
+  // request the gathers of chunk t (and rebuild the sampling state when (tap, dg) changes)
+  auto issue = [&](int t) {
+    const int tap = t / cchunks;
+    const int c0 = (t - tap * cchunks) * BK;
+    const int dg = min(grp * g.Cg + c0, g.C - 1) / g.Cdg;
+    if (tap != cur_tap || dg != cur_dg) {
+      float delta[ND];
+      const int64_t ob = ((int64_t)(b_g * g.DG + dg) * (ND * g.K) + ND * tap) * g.S_o + pix_g;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) delta[a] = offset[ob + (int64_t)a * g.S_o];
+      int tcd[ND];
+      tap_coords<ND>(g, tap, tcd);
+      TapCoef<ND, float> tc;
+      make_tap<ND, float>(g, oc, tcd, delta, false, tc);
+      const float m = MOD ? mask[((int64_t)(b_g * g.DG + dg) * g.K + tap) * g.S_o + pix_g] : 1.f;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        voff[ci] = img_voff + corner_index<ND, float>(tc, ci) * 4;
+        wgt[ci] = corner_weight<ND, float>(tc, ci) * m;
+      }
+      cur_tap = tap;
+      cur_dg = dg;
+    }
+    const int soff = c0 * g.S_i * 4;   // scalar: channel base of this chunk
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+#ifdef ABL_NOGATHER
+        rg[i][ci] = (float)(voff[ci] + soff);
+#else
+        rg[i][ci] = buf_load(r_in, voff[ci], soff + i * g.S_i * 4);
+#endif
+      }
+  };
+  // interpolate the gathered corners and publish the B slab of chunk t
+  auto commit = [&](int t, float *Bb) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      float val = wgt[0] * rg[i][0];
+#pragma unroll
+      for (int ci = 1; ci < NC; ++ci) val = fmaf(wgt[ci], rg[i][ci], val);
+      if (PADK) {   // ragged C_in/groups: rows of the padded K range must be exactly zero
+        const int tap = t / cchunks;
+        const int cl = (t - tap * cchunks) * BK + ksub * CPT + i;
+        val = cl < g.Cg ? val : 0.f;
+      }
+      Bb[(ksub * CPT + i) * BN + j] = val;
+    }
+  };
+  auto load_a = [&](float4 (&ra)[MB][2], int t) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#ifdef ABL_NOWEIGHT
+        ra[i][q] = make_float4(0.5f, 0.25f, 1.f, 2.f);
+#else
+        ra[i][q] = buf_load4(r_wp, a_voff + (i * 2 + q) * 1024, t * slab_bytes);
+#endif
+      }
+  };
+  auto mma = [&](const float4 (&ra)[MB][2], const float *Bbuf) {
+    const float *Bb = Bbuf + wn0 + (lane & 31) + 4 * kh * BN;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float b[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) b[n] = Bb[(8 * q + s) * BN + n * 32];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#ifdef ABL_NOMFMA
+            acc[i][n][s] += a * b[n];
+#else
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[i][n], 0, 0, 0);
+#endif
+        }
+      }
+  };
+
+  // T is even (C_in/groups is padded to 2*BK with zero weights), so the 2x unrolled loop needs no
+  // tail and every prefetch is unconditional: with an `if (t + 1 < T)` around the requests hipcc
+  // lost track of the outstanding-load count and put s_waitcnt vmcnt(0) in front of the MFMAs.
+  float4 ra0[MB][2], ra1[MB][2];
+  load_a(ra0, 0);
+  issue(0);
+  for (int t = 0; t < T; t += 2) {
+    // ---- even chunk: LDS buffer 0, fragments ra0 ----
+    commit(t, Bs);
+#ifndef ABL_NOBARRIER
+    __syncthreads();
+#endif
+    issue(t + 1);
+    load_a(ra1, t + 1);
+    __builtin_amdgcn_sched_barrier(0);   // keep every request above the MFMA phase
+    mma(ra0, Bs);
+    // ---- odd chunk: LDS buffer 1, fragments ra1 ----
+    commit(t + 1, Bs + BK * BN);
+#ifndef ABL_NOBARRIER
+    __syncthreads();
+#endif
+    const int tn = min(t + 2, T - 1);    // past the end: re-request the last chunk, unused
+    issue(tn);
+    load_a(ra0, tn);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(ra1, Bs + BK * BN);
+  }
+
+  // ---- epilogue: + bias, store [B, O, S_o] (lanes 0-31 -> 32 consecutive pixels) ----
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int n_e = n0 + wn0 + q * 32 + (lane & 31);
+    if (n_e < g.N) {
+      const int b_e = n_e / g.S_o;
+      const int pix_e = n_e - b_e * g.S_o;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ol = o0 + wm0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (ol < g.Og) {
+            const int och = grp * g.Og + ol;
+            const float bv = g.with_bias ? bias[och] : 0.f;
+            output[(int64_t)(b_e * g.O + och) * g.S_o + pix_e] = acc[mb][q][r] + bv;
+          }
+        }
+    }
+  }
+}
+
+template <int ND, bool MOD, int BM, int BN, int WM, int WN>
+int launch_fwd_tile(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+                    hipStream_t stream) {
+  const int ntm = (g.Og + BM - 1) / BM;
+  const int ntn = (g.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, g.G);
+  if (g.Cg % (2 * kBK))
+    hipLaunchKernelGGL((mfma_fwd_kernel<ND, MOD, BM, BN, WM, WN, true>), grid, dim3(256), 0, stream,
+                       g, pd, (const float *)t.input, wp, (const float *)t.bias,
+                       (const float *)t.offset, (const float *)t.mask, (float *)t.output, ntm, ntn);
+  else
+    hipLaunchKernelGGL((mfma_fwd_kernel<ND, MOD, BM, BN, WM, WN, false>), grid, dim3(256), 0, stream,
+                       g, pd, (const float *)t.input, wp, (const float *)t.bias,
+                       (const float *)t.offset, (const float *)t.mask, (float *)t.output, ntm, ntn);
+  return check_launch("mfma_fwd");
+}
+
+template <int ND, bool MOD>
+int launch_fwd(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+               hipStream_t stream) {
+  const char *v = getenv("MDCONV_FWD_TILE");   // tuning knob: "256x32" | "256x64"
+  if (pd.BM == 256) {
+    if (v && !strcmp(v, "256x64")) return launch_fwd_tile<ND, MOD, 256, 64, 64, 64>(g, pd, t, wp, stream);
+    return launch_fwd_tile<ND, MOD, 256, 32, 64, 32>(g, pd, t, wp, stream);
+  }
+  if (pd.BM == 128) return launch_fwd_tile<ND, MOD, 128, 64, 64, 32>(g, pd, t, wp, stream);
+  return launch_fwd_tile<ND, MOD, 64, 128, 64, 32>(g, pd, t, wp, stream);
+}
+
+}  // namespace
+
+int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+                     hipStream_t stream) {
+  if (g.nd == 2)
+    return g.modulated ? launch_fwd<2, true>(g, pd, t, wp, stream)
+                       : launch_fwd<2, false>(g, pd, t, wp, stream);
+  return g.modulated ? launch_fwd<3, true>(g, pd, t, wp, stream)
+                     : launch_fwd<3, false>(g, pd, t, wp, stream);
+}
+
+}  // namespace mdconv

@@ -1,0 +1,69 @@
+// mfma_tile.hpp -- shared pieces of the MFMA implicit-GEMM kernels (fp32, gfx950).
+#pragma once
+#include "mdconv_common.hpp"
+
+namespace mdconv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 16;  // K-chunk (channels of one tap) per LDS stage
+
+// Padded dimensions of the packed weight copies kept in the workspace.
+struct PackDims {
+  int Cgp;  // C_in/groups rounded up to 2*kBK
+  int Ogp;  // C_out/groups rounded up to BM
+  int BM;   // output-channel tile of the forward kernel (256 / 128 / 64)
+};
+
+inline PackDims pack_dims(const Geom &g) {
+  PackDims pd;
+  pd.BM = g.Og > 128 ? 256 : (g.Og > 64 ? 128 : 64);
+  pd.Cgp = (g.Cg + 2 * kBK - 1) / (2 * kBK) * (2 * kBK);  // even chunk count (2x unrolled K loops)
+  pd.Ogp = (g.Og + pd.BM - 1) / pd.BM * pd.BM;
+  return pd;
+}
+
+// Map the hardware's round-robin block->XCD placement (block b runs on XCD b % 8,
+// MI355X_MICROARCH.md) to contiguous tile ranges per XCD so neighbouring tiles share an L2.
+// Bijective for any n (cdna_hip_programming.md, "XCD swizzle must be bijective").  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// ---- raw buffer loads: base in an SGPR resource, per-lane byte offset in `voff`, wave-uniform
+// byte offset in `soff` (lives in an SGPR), so the address costs no VALU instruction.  Out of
+// range offsets return 0 instead of faulting (num_records bound). ----
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, size_t bytes) {
+  const unsigned n = bytes > 0xfffffff0ull ? 0xfffffff0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+struct F4bits { float x, y, z, w; };
+__device__ __forceinline__ float4 buf_load4(rsrc_t r, int voff, int soff) {
+  // The builtin returns an opaque 128-bit value: assigning it to an int4 vector SPLATS it
+  // (every component = the first dword, and hipcc then narrows the load to one dword), so
+  // reinterpret the bits through a struct instead.
+  const F4bits f = __builtin_bit_cast(F4bits, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return make_float4(f.x, f.y, f.z, f.w);
+}
+
+// ---- internal entry points (fp32) ----
+// wp : forward A operand in MFMA-fragment order, so a wave reads its 32x8 fragment with ONE fully
+//      coalesced 16-byte-per-lane load:
+//        wp[g][tap][cchunk][mblk][q][lane][s] = W[g*Og + mblk*32 + (lane&31)]
+//                                                [cchunk*16 + 8*q + 4*(lane>>5) + s][tap]
+//      (cchunk < Cgp/16, mblk < Ogp/32, q < 2, s < 4; zero padded).  MFMA step (q, s) multiplies
+//      k = cchunk*16 + 8q + s (lanes 0-31) and k + 4 (lanes 32-63).
+// wq : [G][K][Ogp][Cgp]  (tap-major, input channel contiguous)   -- backward GEMM-1 operand
+int pack_weights_f32(const Geom &g, const PackDims &pd, const float *weight, float *wp, float *wq,
+                     hipStream_t stream);
+int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+                     hipStream_t stream);
+
+}  // namespace mdconv

@@ -84,7 +84,7 @@ def test_error_behaviour_on_device():
     with pytest.raises(RuntimeError, match="channels"):
         M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo[:8], 2, 1, 64, False)
     with pytest.raises(RuntimeError, match="offset shape"):
-        M.modulated_deform_conv2d_forward_cuda(x, w, b, off[:, :10], m, *geo)
+        M.modulated_deform_conv2d_forward_cuda(x, w, b, off[:, :10].contiguous(), m, *geo)
     with pytest.raises(RuntimeError, match="in_step"):
         M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo[:10], 0, False)
     out = M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo)
