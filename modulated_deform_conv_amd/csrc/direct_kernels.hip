@@ -348,9 +348,9 @@ int launch_fwd(const Geom &g, const Tensors &t, hipStream_t stream) {
 }
 
 template <typename T, int ND, bool MOD>
-int launch_bwd(const Geom &g, const Tensors &t, hipStream_t stream) {
+int launch_bwd(const Geom &g, const Tensors &t, hipStream_t stream, int parts) {
   using A = typename Acc<T>::type;
-  {
+  if (parts & 1) {
     constexpr int TO = 32;
     const int cc = pick_cc(g, TO, sizeof(A));
     const size_t smem = (size_t)cc * g.K * TO * sizeof(A);
@@ -367,7 +367,7 @@ int launch_bwd(const Geom &g, const Tensors &t, hipStream_t stream) {
     int rc = check_launch("direct_bwd_data");
     if (rc) return rc;
   }
-  {
+  if (parts & 2) {
     constexpr int TO = 8, CC = 8;
     const int otiles = (g.Og + TO - 1) / TO;
     const int cchunks = (g.Cg + CC - 1) / CC;
@@ -390,15 +390,16 @@ int launch_bwd(const Geom &g, const Tensors &t, hipStream_t stream) {
                        (T *)t.grad_bias);
     return check_launch("direct_bwd_weight");
   }
+  return MDCONV_OK;
 }
 
 template <typename T> int dispatch_fwd(const Geom &g, const Tensors &t, hipStream_t s) {
   if (g.nd == 2) return g.modulated ? launch_fwd<T, 2, true>(g, t, s) : launch_fwd<T, 2, false>(g, t, s);
   return g.modulated ? launch_fwd<T, 3, true>(g, t, s) : launch_fwd<T, 3, false>(g, t, s);
 }
-template <typename T> int dispatch_bwd(const Geom &g, const Tensors &t, hipStream_t s) {
-  if (g.nd == 2) return g.modulated ? launch_bwd<T, 2, true>(g, t, s) : launch_bwd<T, 2, false>(g, t, s);
-  return g.modulated ? launch_bwd<T, 3, true>(g, t, s) : launch_bwd<T, 3, false>(g, t, s);
+template <typename T> int dispatch_bwd(const Geom &g, const Tensors &t, hipStream_t s, int parts) {
+  if (g.nd == 2) return g.modulated ? launch_bwd<T, 2, true>(g, t, s, parts) : launch_bwd<T, 2, false>(g, t, s, parts);
+  return g.modulated ? launch_bwd<T, 3, true>(g, t, s, parts) : launch_bwd<T, 3, false>(g, t, s, parts);
 }
 
 }  // namespace
@@ -413,11 +414,11 @@ int direct_forward(const Geom &g, int dtype, const Tensors &t, hipStream_t strea
   return MDCONV_EINVAL;
 }
 
-int direct_backward(const Geom &g, int dtype, const Tensors &t, hipStream_t stream) {
+int direct_backward(const Geom &g, int dtype, const Tensors &t, hipStream_t stream, int parts) {
   switch (dtype) {
-    case MDCONV_F32: return dispatch_bwd<float>(g, t, stream);
-    case MDCONV_F16: return dispatch_bwd<__half>(g, t, stream);
-    case MDCONV_F64: return dispatch_bwd<double>(g, t, stream);
+    case MDCONV_F32: return dispatch_bwd<float>(g, t, stream, parts);
+    case MDCONV_F16: return dispatch_bwd<__half>(g, t, stream, parts);
+    case MDCONV_F64: return dispatch_bwd<double>(g, t, stream, parts);
   }
   set_error("unknown dtype %d", dtype);
   return MDCONV_EINVAL;

@@ -185,6 +185,7 @@ struct Tensors {
 
 // direct (VALU) path, any shape / dtype
 int direct_forward(const Geom &g, int dtype, const Tensors &t, hipStream_t stream);
-int direct_backward(const Geom &g, int dtype, const Tensors &t, hipStream_t stream);
+// parts: bit 0 = grad_input/grad_offset/grad_mask kernel, bit 1 = grad_weight/grad_bias kernel
+int direct_backward(const Geom &g, int dtype, const Tensors &t, hipStream_t stream, int parts = 3);
 
 }  // namespace mdconv

@@ -1,0 +1,465 @@
+// mfma_bwd_data.hip -- grad_offset / grad_mask / grad_input for fp32 on the gfx950 matrix cores.
+//
+// Reference structure (mdeformable_conv.cu:412-435): GEMM-1 grad_col = W^T . grad_out, then one
+// thread per SAMPLE doing 7 global atomics.  Measured on MI355X (tools/ubench_scatter*.hip) the
+// 925 M float atomics of cfg2 cost 24.6 ms scattered / 2.8 ms perfectly coalesced, and LDS
+// ds_add_f32 is no better (4.7 ms) -- against a 2.3 ms MFMA budget for the whole iteration.
+// So nothing here uses floating-point atomics:
+//
+//  1. mfma_bwd_data_kernel  (col2im_coord + GEMM-1, fused)
+//     M = input channels, N = output pixels, K = output channels.  A = W pre-packed in
+//     MFMA-fragment order (`pack_wq`), B = grad_out slab through LDS.  In the accumulator layout
+//     a lane owns ONE pixel and 32 channels, so grad_offset / grad_mask -- sums over channels of
+//     grad_col * d(sample) -- are reduced in registers, then across the two half-waves with one
+//     shuffle and across channel-waves through LDS, and written once per (tap, pixel) by their
+//     single owner.  grad_col itself is streamed to the workspace as [b][c][tap][pix] (the
+//     reference's grad_columns, per image) for step 3.
+//  2. build_scatter_csr  (count -> scan -> fill, integer atomics only)
+//     inverts the scatter map: for every (image, tap, input pixel q) the list of
+//     (output pixel n, bilinear weight * mask) that land on q.  It depends only on offset / mask.
+//  3. col2im_gather_kernel
+//     grad_input[b][c][q] += sum over the lists of q of weight * grad_col[b][c][tap][n]:
+//     a gather (lanes = consecutive q, taps in lockstep so neighbours read neighbours),
+//     8 channels per list read, plain coalesced read-modify-write of grad_input.
+#include "mfma_kernels.hpp"
+#include "mfma_tile.hpp"
+
+namespace mdconv {
+
+namespace {
+
+int grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+// W[o][c][tap] -> wq[tap][ochunk][cblk][q][lane][s] = W[ochunk*16 + 8q + 4(lane>>5) + s]
+//                                                      [cblk*32 + (lane&31)][tap]   (0 padded)
+__global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int cblks,
+                                                      const float *__restrict__ w,
+                                                      float *__restrict__ wq) {
+  const int64_t total = (int64_t)g.K * ochunks * cblks * 2 * 64;   // float4 units
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int q = (int)(r & 1); r >>= 1;
+    const int cblk = (int)(r % cblks); r /= cblks;
+    const int ochunk = (int)(r % ochunks);
+    const int tap = (int)(r / ochunks);
+    const int c = cblk * 32 + (lane & 31);
+    const int ob = ochunk * 16 + 8 * q + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int o = ob + s;
+      v[s] = (o < g.O && c < g.C) ? w[((int64_t)o * g.C + c) * g.K + tap] : 0.f;
+    }
+    reinterpret_cast<float4 *>(wq)[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. GEMM-1 + coordinate gradients + grad_col stream
+// ---------------------------------------------------------------------------------------------
+template <int ND, bool MOD, int WAVES_C>
+__global__ __launch_bounds__(256) void mfma_bwd_data_kernel(
+    Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
+    const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
+    float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
+    int ntiles) {
+  constexpr int NC = 1 << ND;
+  constexpr int BK = kBK, MB = 2;
+  constexpr int WAVES_P = 4 / WAVES_C;
+  constexpr int BNP = 32 * WAVES_P;        // pixels per workgroup
+  constexpr int BPT = BK * BNP / 256;      // grad_out elements per thread per chunk
+  constexpr int RB = 8;                    // accumulator rows gathered per batch
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * BNP];
+
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int n0 = tile * BNP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5;
+  const int wc = wave / WAVES_P, wp = wave % WAVES_P;
+
+  // the pixel this lane owns in the accumulator layout
+  const int n_raw = n0 + wp * 32 + (lane & 31);
+  const bool live = n_raw < g.N;
+  const int n_l = live ? n_raw : g.N - 1;
+  const int b_l = n_l / g.S_o, pix_l = n_l - b_l * g.S_o;
+  int oc[ND];
+  out_coords<ND>(g, pix_l, oc);
+
+  // grad_out slab: thread -> (pixel j, rows osub*BPT ..)
+  const int j = tid % BNP, osub = tid / BNP;
+  const int n_t = min(n0 + j, g.N - 1);
+  const int b_t = n_t / g.S_o, pix_t = n_t - b_t * g.S_o;
+  const int go_voff = ((b_t * g.O + osub * BPT) * g.S_o + pix_t) * 4;
+  const bool t_live = n0 + j < g.N;
+
+  const int T_o = bd.ochunks;                         // even
+  const int passes = bd.cblks_q / (2 * WAVES_C);
+  const int frag_bytes = 64 * 16;                      // one [lane][4] fragment
+  const int chunk_bytes = bd.cblks_q * 2 * frag_bytes; // one ochunk of wq
+  const rsrc_t r_in = make_rsrc(input, (size_t)g.B * g.C * g.S_i * 4);
+  const rsrc_t r_go = make_rsrc(gout, (size_t)g.B * g.O * g.S_o * 4);
+  const rsrc_t r_wq = make_rsrc(wq, (size_t)g.K * T_o * chunk_bytes);
+  const rsrc_t r_gc = make_rsrc(gcol, (size_t)g.B * g.C * g.K * g.S_o * 4);
+  const int a_lane = lane * 16;
+
+  for (int tap = 0; tap < g.K; ++tap) {
+    // ---- sampling state of (tap, this lane's pixel) ----
+    int voff[NC];
+    float w[NC], dw[ND][NC];
+    float m = 1.f;
+    bool inside;
+    {
+      float delta[ND];
+      const int64_t ob = ((int64_t)b_l * (ND * g.K) + ND * tap) * g.S_o + pix_l;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) delta[a] = offset[ob + (int64_t)a * g.S_o];
+      int tcd[ND];
+      tap_coords<ND>(g, tap, tcd);
+      TapCoef<ND, float> tc;
+      make_tap<ND, float>(g, oc, tcd, delta, true, tc);
+      if (MOD) m = mask[((int64_t)b_l * g.K + tap) * g.S_o + pix_l];
+      inside = tc.inside;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        voff[ci] = (b_l * g.C * g.S_i + corner_index<ND, float>(tc, ci) + 4 * kh * g.S_i) * 4;
+        w[ci] = corner_weight<ND, float>(tc, ci);
+#pragma unroll
+        for (int a = 0; a < ND; ++a) dw[a][ci] = corner_dweight<ND, float>(tc, ci, a);
+      }
+    }
+    const int gc_voff = (((b_l * g.C + 4 * kh) * g.K + tap) * g.S_o + pix_l) * 4;
+    float goff[ND], gm = 0.f;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) goff[a] = 0.f;
+
+    for (int pass = 0; pass < passes; ++pass) {
+      const int cbase = (pass * WAVES_C + wc) * 64;       // this wave's 64 channels
+      const int a_soff0 = tap * T_o * chunk_bytes + (cbase / 32) * 2 * frag_bytes;
+      f32x16 acc[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+      float rb[BPT];
+      auto load_b = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) rb[i] = buf_load(r_go, go_voff, (t * 16 + i) * g.S_o * 4);
+      };
+      auto commit_b = [&](float *Bb) {
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) Bb[(osub * BPT + i) * BNP + j] = t_live ? rb[i] : 0.f;
+      };
+      auto load_a = [&](float4 (&ra)[MB][2], int t) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            ra[i][q] = buf_load4(r_wq, a_lane + (i * 2 + q) * frag_bytes, a_soff0 + t * chunk_bytes);
+      };
+      auto mma = [&](const float4 (&ra)[MB][2], const float *Bbuf) {
+        const float *Bb = Bbuf + wp * 32 + (lane & 31) + 4 * kh * BNP;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float b = Bb[(8 * q + s) * BNP];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+              const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            }
+          }
+      };
+
+      float4 ra0[MB][2], ra1[MB][2];
+      load_a(ra0, 0);
+      load_b(0);
+      for (int t = 0; t < T_o; t += 2) {
+        commit_b(smem);
+        __syncthreads();
+        load_b(t + 1);
+        load_a(ra1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ra0, smem);
+        commit_b(smem + BK * BNP);
+        __syncthreads();
+        const int tn = min(t + 2, T_o - 1);
+        load_b(tn);
+        load_a(ra0, tn);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ra1, smem + BK * BNP);
+      }
+
+      // ---- epilogue of (tap, pass): lane = pixel, acc rows = channels ----
+      if (cbase < g.C) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r0 = 0; r0 < 16; r0 += RB) {
+            float v[RB][NC];
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+              const int r = r0 + rr;
+              const int cu = cbase + mb * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh is in the voffset
+              const int cs = min(cu, g.C - 5) * g.S_i * 4;   // cu % 8 < 4, so C-5 is the last valid one
+#pragma unroll
+              for (int ci = 0; ci < NC; ++ci) v[rr][ci] = buf_load(r_in, voff[ci], cs);
+            }
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+              const int r = r0 + rr;
+              const int cu = cbase + mb * 32 + (r & 3) + 8 * (r >> 2);
+              if (cu < g.C) {   // wave-uniform (C % 8 == 0)
+                const float gc = acc[mb][r];
+                if (live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gc), r_gc, gc_voff,
+                                                                cu * g.K * g.S_o * 4, 0);
+                float val = w[0] * v[rr][0];
+#pragma unroll
+                for (int ci = 1; ci < NC; ++ci) val = fmaf(w[ci], v[rr][ci], val);
+                gm = fmaf(gc, val, gm);
+#pragma unroll
+                for (int a = 0; a < ND; ++a) {
+                  float dv = dw[a][0] * v[rr][0];
+#pragma unroll
+                  for (int ci = 1; ci < NC; ++ci) dv = fmaf(dw[a][ci], v[rr][ci], dv);
+                  goff[a] = fmaf(gc, dv, goff[a]);
+                }
+              }
+            }
+          }
+      }
+    }
+
+    // ---- reduce over channels: the two half-waves, then the WAVES_C channel-waves ----
+#pragma unroll
+    for (int a = 0; a < ND; ++a) goff[a] += __shfl_xor(goff[a], 32, 64);
+    gm += __shfl_xor(gm, 32, 64);
+    if (WAVES_C > 1) {
+      __syncthreads();   // every wave is done with the LDS slabs of this tap
+      float *red = smem;   // [WAVES_C][ND + 1][BNP]
+      if (kh == 0 && wc > 0) {
+#pragma unroll
+        for (int a = 0; a < ND; ++a) red[(wc * (ND + 1) + a) * BNP + wp * 32 + lane] = goff[a];
+        red[(wc * (ND + 1) + ND) * BNP + wp * 32 + lane] = gm;
+      }
+      __syncthreads();
+      if (kh == 0 && wc == 0) {
+#pragma unroll
+        for (int x = 1; x < WAVES_C; ++x) {
+#pragma unroll
+          for (int a = 0; a < ND; ++a) goff[a] += red[(x * (ND + 1) + a) * BNP + wp * 32 + lane];
+          gm += red[(x * (ND + 1) + ND) * BNP + wp * 32 + lane];
+        }
+      }
+      __syncthreads();   // red is overwritten by the next tap's first slab
+    }
+    if (kh == 0 && wc == 0 && live) {
+      // single owner of (b, tap, pix): plain accumulate (the C ABI accumulates into grads)
+      if (!g.range_gate || inside) {
+        const int64_t ob = ((int64_t)b_l * (ND * g.K) + ND * tap) * g.S_o + pix_l;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) grad_offset[ob + (int64_t)a * g.S_o] += goff[a] * m;
+      }
+      if (MOD) grad_mask[((int64_t)b_l * g.K + tap) * g.S_o + pix_l] += gm;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. inverse scatter map (CSR keyed by (b, tap, q)); DG == 1
+// ---------------------------------------------------------------------------------------------
+template <int ND, bool MOD, bool FILL>
+__global__ __launch_bounds__(256) void csr_pass_kernel(Geom g, const float *__restrict__ offset,
+                                                       const float *__restrict__ mask,
+                                                       int *__restrict__ cnt_or_cursor,
+                                                       const int *__restrict__ rowptr,
+                                                       int2 *__restrict__ entries) {
+  constexpr int NC = 1 << ND;
+  const int64_t total = (int64_t)g.B * g.K * g.S_o;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int pix = (int)(i % g.S_o);
+    const int tap = (int)((i / g.S_o) % g.K);
+    const int b = (int)(i / g.S_o / g.K);
+    int oc[ND], tcd[ND];
+    out_coords<ND>(g, pix, oc);
+    tap_coords<ND>(g, tap, tcd);
+    float delta[ND];
+    const int64_t ob = ((int64_t)b * (ND * g.K) + ND * tap) * g.S_o + pix;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) delta[a] = offset[ob + (int64_t)a * g.S_o];
+    TapCoef<ND, float> tc;
+    make_tap<ND, float>(g, oc, tcd, delta, true, tc);
+    const float m = MOD ? mask[((int64_t)b * g.K + tap) * g.S_o + pix] : 1.f;
+    const int64_t seg = (int64_t)(b * g.K + tap);
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+      const float wa = corner_weight_atom<ND, float>(tc, ci);   // validity folded in
+      if (wa != 0.f) {
+        const int q = corner_index<ND, float>(tc, ci);
+        if (!FILL) {
+          atomicAdd(cnt_or_cursor + seg * g.S_i + q, 1);
+        } else {
+          const int pos = rowptr[seg * (g.S_i + 1) + q] + atomicAdd(cnt_or_cursor + seg * g.S_i + q, 1);
+          entries[seg * ((int64_t)g.S_o * NC) + pos] = make_int2(pix, __float_as_int(wa * m));
+        }
+      }
+    }
+  }
+}
+
+// exclusive scan of cnt[seg][0..S_i) -> rowptr[seg][0..S_i], one workgroup per segment
+__global__ __launch_bounds__(256) void csr_scan_kernel(int S_i, const int *__restrict__ cnt,
+                                                       int *__restrict__ rowptr) {
+  __shared__ int wsum[4];
+  __shared__ int carry;
+  const int seg = blockIdx.x;
+  const int *c = cnt + (int64_t)seg * S_i;
+  int *rp = rowptr + (int64_t)seg * (S_i + 1);
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < S_i; base += 256) {
+    const int i = base + threadIdx.x;
+    const int v = i < S_i ? c[i] : 0;
+    int x = v;   // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(x, d, 64);
+      if ((threadIdx.x & 63) >= d) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) woff += wsum[k];
+    const int excl = carry + woff + x - v;
+    if (i < S_i) rp[i] = excl;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = excl + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rp[S_i] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. grad_input[b][c][q] += sum_{tap} sum_{e in list(b, tap, q)} w_e * gcol[b][c][tap][n_e]
+// workgroup = 64 consecutive q x 4 channel groups; CH channels per list read.
+// ---------------------------------------------------------------------------------------------
+template <int ND, int CH>
+__global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float *__restrict__ gcol,
+                                                            const int *__restrict__ rowptr,
+                                                            const int2 *__restrict__ entries,
+                                                            float *__restrict__ grad_input) {
+  constexpr int NC = 1 << ND;
+  const int qtiles = (g.S_i + 63) / 64;
+  const int b = blockIdx.x / qtiles;
+  const int q = (blockIdx.x - b * qtiles) * 64 + (threadIdx.x & 63);
+  const int cgrp = threadIdx.x >> 6;                 // 0..3
+  const bool live = q < g.S_i;
+  const int qq = live ? q : g.S_i - 1;
+  const int64_t plane = (int64_t)g.K * g.S_o;         // one channel of gcol
+  for (int c0 = blockIdx.y * (4 * CH) + cgrp * CH; c0 < g.C; c0 += gridDim.y * 4 * CH) {
+    float acc[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) acc[i] = 0.f;
+    const float *gc = gcol + ((int64_t)b * g.C + c0) * plane;
+    for (int tap = 0; tap < g.K; ++tap) {
+      const int64_t seg = (int64_t)(b * g.K + tap);
+      const int *rp = rowptr + seg * (g.S_i + 1) + qq;
+      const int e0 = rp[0], e1 = live ? rp[1] : e0;
+      const int2 *ent = entries + seg * ((int64_t)g.S_o * NC);
+      const float *gt = gc + (int64_t)tap * g.S_o;
+      for (int e = e0; e < e1; ++e) {
+        const int2 en = ent[e];
+        const float we = __int_as_float(en.y);
+        const float *src = gt + en.x;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if (c0 + i < g.C) acc[i] = fmaf(we, src[(int64_t)i * plane], acc[i]);
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i)
+        if (c0 + i < g.C) grad_input[((int64_t)b * g.C + c0 + i) * g.S_i + q] += acc[i];
+    }
+  }
+}
+
+}  // namespace
+
+int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream) {
+  const int64_t total = (int64_t)g.K * bd.ochunks * bd.cblks_q * 2 * 64;
+  hipLaunchKernelGGL(pack_wq_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, bd.ochunks,
+                     bd.cblks_q, weight, wq);
+  return check_launch("pack_wq");
+}
+
+int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
+                      float *gcol, hipStream_t stream) {
+#define LAUNCH_BD(ND, MOD, WC)                                                                  \
+  do {                                                                                          \
+    const int bnp = 32 * (4 / WC);                                                              \
+    const int ntiles = (g.N + bnp - 1) / bnp;                                                   \
+    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC>), dim3(ntiles), dim3(256), 0, stream, \
+                       g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
+                       (const float *)t.offset, (const float *)t.mask, gcol,                    \
+                       (float *)t.grad_offset, (float *)t.grad_mask, ntiles);                   \
+  } while (0)
+#define LAUNCH_BD2(ND, MOD)                                                                     \
+  do {                                                                                          \
+    if (bd.waves_c == 4) LAUNCH_BD(ND, MOD, 4);                                                 \
+    else if (bd.waves_c == 2) LAUNCH_BD(ND, MOD, 2);                                            \
+    else LAUNCH_BD(ND, MOD, 1);                                                                 \
+  } while (0)
+  if (g.nd == 2) { if (g.modulated) LAUNCH_BD2(2, true); else LAUNCH_BD2(2, false); }
+  else { if (g.modulated) LAUNCH_BD2(3, true); else LAUNCH_BD2(3, false); }
+#undef LAUNCH_BD2
+#undef LAUNCH_BD
+  return check_launch("mfma_bwd_data");
+}
+
+int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol, int *cnt,
+               int *rowptr, void *entries, hipStream_t stream) {
+  const int64_t samples = (int64_t)g.B * g.K * g.S_o;
+  const size_t cnt_bytes = (size_t)g.B * g.K * g.S_i * sizeof(int);
+  hipError_t e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
+  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
+#define LAUNCH_CSR(ND, MOD, FILL)                                                               \
+  hipLaunchKernelGGL((csr_pass_kernel<ND, MOD, FILL>), dim3(grid_for(samples)), dim3(256), 0,   \
+                     stream, g, (const float *)t.offset, (const float *)t.mask, cnt, rowptr,    \
+                     (int2 *)entries)
+#define LAUNCH_CSR2(FILL)                                                                       \
+  do {                                                                                          \
+    if (g.nd == 2) { if (g.modulated) LAUNCH_CSR(2, true, FILL); else LAUNCH_CSR(2, false, FILL); } \
+    else { if (g.modulated) LAUNCH_CSR(3, true, FILL); else LAUNCH_CSR(3, false, FILL); }      \
+  } while (0)
+  LAUNCH_CSR2(false);
+  int rc = check_launch("csr_count");
+  if (rc) return rc;
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B * g.K), dim3(256), 0, stream, g.S_i, cnt, rowptr);
+  if ((rc = check_launch("csr_scan"))) return rc;
+  e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
+  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
+  LAUNCH_CSR2(true);
+  if ((rc = check_launch("csr_fill"))) return rc;
+#undef LAUNCH_CSR2
+#undef LAUNCH_CSR
+  const int qtiles = (g.S_i + 63) / 64;
+  constexpr int CH = 8;
+  int cy = (g.C + 4 * CH - 1) / (4 * CH);
+  if (cy > 64) cy = 64;
+  const dim3 grid(g.B * qtiles, cy);
+  if (g.nd == 2)
+    hipLaunchKernelGGL((col2im_gather_kernel<2, CH>), grid, dim3(256), 0, stream, g, gcol, rowptr,
+                       (const int2 *)entries, (float *)t.grad_input);
+  else
+    hipLaunchKernelGGL((col2im_gather_kernel<3, CH>), grid, dim3(256), 0, stream, g, gcol, rowptr,
+                       (const int2 *)entries, (float *)t.grad_input);
+  (void)bd;
+  return check_launch("col2im_gather");
+}
+
+}  // namespace mdconv

@@ -1,0 +1,327 @@
+// mfma_bwd_weight.hip -- grad_weight (+ grad_bias) as a fused implicit GEMM (fp32, gfx950).
+//
+//   grad_W[o, (tap, c)] += sum_n grad_out[o, n] * col[(tap, c), n],   n = flattened (b, pix)
+//
+// the reference's GEMM-2 (mdeformable_conv.cu:436-439) with the `columns` operand re-gathered on
+// the fly instead of being re-materialised by the gradient kernel (mdeformable_conv.cu:316).
+// M = output channels, N = 32 input channels of one tap, K = pixels, split over `splits`
+// workgroups whose partial tiles are summed by a small reduction kernel.
+//
+// Same VALU-starved structure as the forward kernel (see mfma_fwd.hip): both operands arrive by
+// raw buffer loads whose addresses live in SGPRs / lane constants:
+//   * A = grad_out, pre-packed once per call in MFMA-fragment order (`pack_gout`);
+//   * B = col slab [16 pixels][32 channels]: a thread owns (pixel kk, channels sub, sub+16); the
+//     sampling state of (tap, pixel) changes every chunk, so it is NOT recomputed here (that
+//     would be ~60 VALU per chunk) but read from the per-call `tap table` (byte offsets + weights
+//     of the 2^ND corners, built by `build_tap_table`), two chunks ahead;
+//   * LDS holds only the B slab (double buffered, pitch 33 so the transposing write is at most
+//     2-way conflicted, which is free for ds_write_b32).
+#include "mfma_kernels.hpp"
+#include "mfma_tile.hpp"
+
+namespace mdconv {
+
+namespace {
+
+constexpr int kPitch = 33;
+
+// ---------------------------------------------------------------------------------------------
+// tap table: per (dg, tap, n) the 2^ND corner byte offsets (image base folded in) and weights
+// (validity, backward load gating and the mask folded in).  Entry = [2][NC] words.
+// ---------------------------------------------------------------------------------------------
+template <int ND, bool MOD>
+__global__ __launch_bounds__(256) void tap_table_kernel(Geom g, int Np, const float *__restrict__ offset,
+                                                        const float *__restrict__ mask,
+                                                        int *__restrict__ table) {
+  constexpr int NC = 1 << ND;
+  const int64_t total = (int64_t)g.DG * g.K * Np;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i % Np);
+    const int tap = (int)((i / Np) % g.K);
+    const int dg = (int)(i / Np / g.K);
+    int vo[NC];
+    float w[NC];
+    if (n < g.N) {
+      const int b = n / g.S_o, pix = n - b * g.S_o;
+      int oc[ND], tcd[ND];
+      out_coords<ND>(g, pix, oc);
+      tap_coords<ND>(g, tap, tcd);
+      float delta[ND];
+      const int64_t ob = ((int64_t)(b * g.DG + dg) * (ND * g.K) + ND * tap) * g.S_o + pix;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) delta[a] = offset[ob + (int64_t)a * g.S_o];
+      TapCoef<ND, float> tc;
+      make_tap<ND, float>(g, oc, tcd, delta, true, tc);
+      const float m = MOD ? mask[((int64_t)(b * g.DG + dg) * g.K + tap) * g.S_o + pix] : 1.f;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        vo[ci] = (b * g.C * g.S_i + corner_index<ND, float>(tc, ci)) * 4;
+        w[ci] = corner_weight<ND, float>(tc, ci) * m;
+      }
+    } else {
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) { vo[ci] = 0; w[ci] = 0.f; }
+    }
+    int *e = table + i * (2 * NC);
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+      e[ci] = vo[ci];
+      e[NC + ci] = __float_as_int(w[ci]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grad_out [B, O, S_o] -> A fragments: ga[nchunk][mblk][q][lane][s] =
+//   grad_out[o = mblk*32 + (lane&31)][n = nchunk*16 + 8q + 4(lane>>5) + s]   (0 outside)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_gout_kernel(Geom g, int Np, int mblks,
+                                                        const float *__restrict__ gout,
+                                                        float *__restrict__ ga) {
+  const int64_t total = (int64_t)(Np / 16) * mblks * 2 * 64;   // float4 units
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int q = (int)(r & 1); r >>= 1;
+    const int mblk = (int)(r % mblks);
+    const int nchunk = (int)(r / mblks);
+    const int o = mblk * 32 + (lane & 31);
+    const int nb = nchunk * 16 + 8 * q + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int n = nb + s;
+      if (o < g.O && n < g.N) {
+        const int b = n / g.S_o, pix = n - b * g.S_o;
+        v[s] = gout[(int64_t)(b * g.O + o) * g.S_o + pix];
+      } else {
+        v[s] = 0.f;
+      }
+    }
+    reinterpret_cast<float4 *>(ga)[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the GEMM
+// ---------------------------------------------------------------------------------------------
+template <int ND, bool PADN>
+__global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd,
+                                                              const float *__restrict__ input,
+                                                              const float *__restrict__ ga,
+                                                              const int *__restrict__ table,
+                                                              float *__restrict__ part) {
+  constexpr int NC = 1 << ND;
+  constexpr int BK = kBK, BN = 32, MB = 2;
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BK * kPitch];
+
+  // blockIdx.x = (mtile * K + tap) * cblks + cblk ; blockIdx.y = split
+  int id = blockIdx.x;
+  const int cblk = id % bd.cblks; id /= bd.cblks;
+  const int tap = id % g.K;
+  const int mtile = id / g.K;
+  const int split = blockIdx.y;
+  const int c0 = cblk * 32;
+  const int dg = min(c0, g.C - 1) / g.Cdg;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5;
+  const int kk = tid & 15, sub = tid >> 4;   // pixel within the chunk, channel within the tile
+
+  const int pairs_total = bd.Np / 32;
+  const int p_begin = split * bd.pairs_per_split;
+  const int p_end = min(p_begin + bd.pairs_per_split, pairs_total);
+  const int t_begin = 2 * p_begin, t_end = 2 * p_end;   // chunk range (16 pixels each), even count
+
+  const rsrc_t r_in = make_rsrc(input, (size_t)g.B * g.C * g.S_i * sizeof(float));
+  const int slab_bytes = bd.mblks * 2 * 64 * 16;
+  const rsrc_t r_ga = make_rsrc(ga, (size_t)(bd.Np / 16) * slab_bytes);
+  const int entry_bytes = 2 * NC * 4;
+  const rsrc_t r_tab = make_rsrc(table + (size_t)(dg * g.K + tap) * bd.Np * (2 * NC),
+                                 (size_t)bd.Np * entry_bytes);
+  const int a_voff = ((mtile * 8 + wave * MB) * 2 * 64 + lane) * 16;
+  const int t_voff = kk * entry_bytes;
+  const int chan_voff = (c0 + sub) * g.S_i * 4;   // this thread's first channel plane
+  const int chan_soff = 16 * g.S_i * 4;           // its second channel is 16 planes further
+
+  f32x16 acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  struct Tab { int vo[NC]; float w[NC]; };
+  auto load_tab = [&](Tab &tb, int t) {
+    const int soff = t * 16 * entry_bytes;
+#pragma unroll
+    for (int h = 0; h < NC / 4; ++h) {
+      const float4 a = buf_load4(r_tab, t_voff + h * 16, soff);
+      tb.vo[4 * h + 0] = __float_as_int(a.x); tb.vo[4 * h + 1] = __float_as_int(a.y);
+      tb.vo[4 * h + 2] = __float_as_int(a.z); tb.vo[4 * h + 3] = __float_as_int(a.w);
+      const float4 b = buf_load4(r_tab, t_voff + NC * 4 + h * 16, soff);
+      tb.w[4 * h + 0] = b.x; tb.w[4 * h + 1] = b.y; tb.w[4 * h + 2] = b.z; tb.w[4 * h + 3] = b.w;
+    }
+  };
+  float rg[2][NC];
+  auto gather = [&](const Tab &tb) {
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+      const int vo = tb.vo[ci] + chan_voff;
+      rg[0][ci] = buf_load(r_in, vo, 0);
+      rg[1][ci] = buf_load(r_in, vo, chan_soff);
+    }
+  };
+  auto commit = [&](const Tab &tb, int t, float *Bb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float val = tb.w[0] * rg[i][0];
+#pragma unroll
+      for (int ci = 1; ci < NC; ++ci) val = fmaf(tb.w[ci], rg[i][ci], val);
+      if (PADN) val = (t * 16 + kk < g.N) ? val : 0.f;
+      Bb[kk * kPitch + sub + 16 * i] = val;
+    }
+  };
+  auto load_a = [&](float4 (&ra)[MB][2], int t) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) ra[i][q] = buf_load4(r_ga, a_voff + (i * 2 + q) * 1024, t * slab_bytes);
+  };
+  auto mma = [&](const float4 (&ra)[MB][2], const float *Bbuf) {
+    const float *Bb = Bbuf + (lane & 31) + 4 * kh * kPitch;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float b = Bb[(8 * q + s) * kPitch];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+      }
+  };
+
+  if (t_begin < t_end) {
+    const int t_last = t_end - 1;
+    Tab tabA, tabB;
+    float4 ra0[MB][2], ra1[MB][2];
+    load_tab(tabA, t_begin);
+    load_tab(tabB, t_begin + 1);
+    load_a(ra0, t_begin);
+    gather(tabA);
+    for (int t = t_begin; t < t_end; t += 2) {
+      // ---- even chunk ----
+      commit(tabA, t, Bs);
+      __syncthreads();
+      gather(tabB);                         // chunk t+1
+      load_tab(tabA, min(t + 2, t_last));   // chunk t+2
+      load_a(ra1, t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(ra0, Bs);
+      // ---- odd chunk ----
+      commit(tabB, t + 1, Bs + BK * kPitch);
+      __syncthreads();
+      gather(tabA);                         // chunk t+2 (or a harmless repeat at the end)
+      load_tab(tabB, min(t + 3, t_last));
+      load_a(ra0, min(t + 2, t_last));
+      __builtin_amdgcn_sched_barrier(0);
+      mma(ra1, Bs + BK * kPitch);
+    }
+  }
+
+  // partial tile -> part[split][tap][o][c]   (lanes 0-31 = 32 consecutive channels)
+  float *dst = part + ((size_t)(split * g.K + tap) * bd.OgpB) * bd.Cp + c0 + (lane & 31);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = mtile * 256 + wave * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      dst[(size_t)o * bd.Cp] = acc[mb][r];
+    }
+}
+
+// grad_weight[o][c][tap] += sum_split part[split][tap][o][c]
+__global__ __launch_bounds__(256) void reduce_weight_kernel(Geom g, BwdDims bd,
+                                                            const float *__restrict__ part,
+                                                            float *__restrict__ grad_weight) {
+  const int64_t total = (int64_t)g.K * g.O * g.C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % g.C);
+    const int o = (int)((i / g.C) % g.O);
+    const int tap = (int)(i / g.C / g.O);
+    float s = 0.f;
+    for (int sp = 0; sp < bd.splits; ++sp)
+      s += part[((size_t)(sp * g.K + tap) * bd.OgpB + o) * bd.Cp + c];
+    grad_weight[((int64_t)o * g.C + c) * g.K + tap] += s;
+  }
+}
+
+// grad_bias[o] += sum_{b, pix} grad_out[b][o][pix]   (mdeformable_conv.cu:440-444)
+__global__ __launch_bounds__(256) void grad_bias_kernel(Geom g, const float *__restrict__ gout,
+                                                        float *__restrict__ grad_bias) {
+  __shared__ float red[4];
+  const int o = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < g.B; ++b) {
+    const float *row = gout + (int64_t)(b * g.O + o) * g.S_o;
+    for (int i = threadIdx.x; i < g.S_o; i += 256) s += row[i];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) grad_bias[o] += red[0] + red[1] + red[2] + red[3];
+}
+
+int grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+int build_tap_table_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *table,
+                        hipStream_t stream) {
+  const int64_t total = (int64_t)g.DG * g.K * bd.Np;
+  const dim3 grid(grid_for(total));
+#define LAUNCH_TT(ND, MOD)                                                                     \
+  hipLaunchKernelGGL((tap_table_kernel<ND, MOD>), grid, dim3(256), 0, stream, g, bd.Np,          \
+                     (const float *)t.offset, (const float *)t.mask, table)
+  if (g.nd == 2) { if (g.modulated) LAUNCH_TT(2, true); else LAUNCH_TT(2, false); }
+  else { if (g.modulated) LAUNCH_TT(3, true); else LAUNCH_TT(3, false); }
+#undef LAUNCH_TT
+  return check_launch("tap_table");
+}
+
+int pack_gout_f32(const Geom &g, const BwdDims &bd, const float *gout, float *ga,
+                  hipStream_t stream) {
+  const int64_t total = (int64_t)(bd.Np / 16) * bd.mblks * 2 * 64;
+  hipLaunchKernelGGL(pack_gout_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, bd.Np,
+                     bd.mblks, gout, ga);
+  return check_launch("pack_gout");
+}
+
+int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
+                        const int *table, float *part, hipStream_t stream) {
+  const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
+  const bool padn = bd.Np != g.N;
+#define LAUNCH_BW(ND, PADN)                                                                    \
+  hipLaunchKernelGGL((mfma_bwd_weight_kernel<ND, PADN>), grid, dim3(256), 0, stream, g, bd,      \
+                     (const float *)t.input, ga, table, part)
+  if (g.nd == 2) { if (padn) LAUNCH_BW(2, true); else LAUNCH_BW(2, false); }
+  else { if (padn) LAUNCH_BW(3, true); else LAUNCH_BW(3, false); }
+#undef LAUNCH_BW
+  int rc = check_launch("mfma_bwd_weight");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_weight_kernel, dim3(grid_for((int64_t)g.K * g.O * g.C)), dim3(256), 0,
+                     stream, g, bd, part, (float *)t.grad_weight);
+  if ((rc = check_launch("reduce_weight"))) return rc;
+  if (g.with_bias) {
+    hipLaunchKernelGGL(grad_bias_kernel, dim3(g.O), dim3(256), 0, stream, g,
+                       (const float *)t.grad_output, (float *)t.grad_bias);
+    rc = check_launch("grad_bias");
+  }
+  return rc;
+}
+
+}  // namespace mdconv

@@ -45,19 +45,57 @@ int pack_weights_f32(const Geom &g, const PackDims &pd, const float *weight, flo
   return check_launch("pack_weights");
 }
 
+BwdDims bwd_dims(const Geom &g) {
+  BwdDims bd;
+  bd.Np = (g.N + 31) / 32 * 32;
+  bd.OgpB = (g.O + 255) / 256 * 256;
+  bd.mblks = bd.OgpB / 32;
+  bd.mtiles = bd.OgpB / 256;
+  bd.Cp = (g.C + 31) / 32 * 32;
+  bd.cblks = bd.Cp / 32;
+  const int col_tiles = bd.mtiles * g.K * bd.cblks;
+  const int pairs = bd.Np / 32;
+  int splits = (1024 + col_tiles - 1) / col_tiles;       // ~4 workgroups per CU
+  if (splits > pairs) splits = pairs;
+  if (splits < 1) splits = 1;
+  bd.pairs_per_split = (pairs + splits - 1) / splits;
+  bd.splits = (pairs + bd.pairs_per_split - 1) / bd.pairs_per_split;
+  bd.ochunks = (g.O + 31) / 32 * 2;
+  bd.waves_c = g.C > 128 ? 4 : (g.C > 64 ? 2 : 1);
+  bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
+  const int nc = 1 << g.nd;
+  size_t off = 0;
+  bd.off_wq = off;   off += align_up((size_t)g.K * bd.ochunks * bd.cblks_q * 2 * 64 * 16);
+  bd.off_ga = off;   off += align_up((size_t)bd.Np * bd.OgpB * sizeof(float));
+  bd.off_table = off; off += align_up((size_t)g.DG * g.K * bd.Np * 2 * (1 << g.nd) * sizeof(int));
+  bd.off_part = off; off += align_up((size_t)bd.splits * g.K * bd.OgpB * bd.Cp * sizeof(float));
+  bd.off_gcol = off; off += align_up((size_t)g.B * g.C * g.K * g.S_o * sizeof(float));
+  bd.off_cnt = off;  off += align_up((size_t)g.B * g.K * g.S_i * sizeof(int));
+  bd.off_rowptr = off; off += align_up((size_t)g.B * g.K * (g.S_i + 1) * sizeof(int));
+  bd.off_entries = off; off += align_up((size_t)g.B * g.K * g.S_o * nc * 8);
+  bd.off_end = off;
+  return bd;
+}
+
 bool mfma_supported(const Geom &g, int dtype, bool backward) {
   if (dtype != MDCONV_F32) return false;
   if (g.Cg < 16 || g.Og < 16) return false;  // MFMA tiles would be mostly padding
-  if (!(g.DG == 1 || (g.Cdg % kBK == 0 && g.Cg % kBK == 0))) return false;
-  if (backward) return false;                // backward kernels land next
+  if (!(g.DG == 1 || (g.Cdg % (2 * kBK) == 0 && g.Cg % (2 * kBK) == 0))) return false;
+  // raw buffer addressing: every tensor must stay below 2 GiB
+  if ((size_t)g.B * g.C * g.S_i * sizeof(float) >= ((size_t)1 << 31)) return false;
+  if (backward) {
+    if (g.G != 1 || g.DG != 1 || g.C % 8) return false;
+    if ((size_t)g.B * g.O * g.S_o * sizeof(float) >= ((size_t)1 << 31)) return false;
+    if ((size_t)g.B * g.C * g.K * g.S_o * sizeof(float) >= ((size_t)1 << 31)) return false;  // grad_col
+  }
   return true;
 }
 
 size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
   (void)dtype;
+  if (backward) return bwd_dims(g).off_end;
   const PackDims pd = pack_dims(g);
-  const size_t wbytes = align_up((size_t)g.G * g.K * pd.Cgp * pd.Ogp * sizeof(float));
-  return backward ? 2 * wbytes : wbytes;
+  return align_up((size_t)g.G * g.K * pd.Cgp * pd.Ogp * sizeof(float));
 }
 
 int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
@@ -69,9 +107,26 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
   return mfma_forward_f32(g, pd, t, wp, stream);
 }
 
-int mfma_backward(const Geom &, int, const Tensors &, void *, hipStream_t) {
-  set_error("mfma backward not implemented");
-  return MDCONV_EUNSUPPORTED;
+int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  const BwdDims bd = bwd_dims(g);
+  char *base = (char *)ws;
+  float *ga = (float *)(base + bd.off_ga);
+  int *table = (int *)(base + bd.off_table);
+  float *part = (float *)(base + bd.off_part);
+  float *wq = (float *)(base + bd.off_wq);
+  float *gcol = (float *)(base + bd.off_gcol);
+  int rc;
+  (void)dtype;
+  // grad_offset / grad_mask (+ grad_col), then grad_input through the inverted scatter map
+  if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
+  if ((rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, stream))) return rc;
+  if ((rc = col2im_f32(g, bd, t, gcol, (int *)(base + bd.off_cnt), (int *)(base + bd.off_rowptr),
+                       base + bd.off_entries, stream)))
+    return rc;
+  // grad_weight / grad_bias
+  if ((rc = build_tap_table_f32(g, bd, t, table, stream))) return rc;
+  if ((rc = pack_gout_f32(g, bd, (const float *)t.grad_output, ga, stream))) return rc;
+  return mfma_bwd_weight_f32(g, bd, t, ga, table, part, stream);
 }
 
 }  // namespace mdconv

@@ -53,6 +53,19 @@ __device__ __forceinline__ float4 buf_load4(rsrc_t r, int voff, int soff) {
   return make_float4(f.x, f.y, f.z, f.w);
 }
 
+// Dimensions / workspace layout of the MFMA backward (fp32, groups == 1).
+struct BwdDims {
+  int Np;               // B*S_o rounded up to 32 (even number of 16-pixel chunks)
+  int OgpB, mblks, mtiles;   // C_out rounded up to 256; /32; /256
+  int Cp, cblks;        // C_in rounded up to 32; /32
+  int splits, pairs_per_split;   // split-K of the grad_weight GEMM over pixel-chunk pairs
+  int ochunks;          // C_out rounded up to 32, /16 (even): K chunks of GEMM-1
+  int waves_c, cblks_q; // GEMM-1: waves along channels (4/2/1), 32-channel blocks of wq
+  // workspace byte offsets
+  size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_end;
+};
+BwdDims bwd_dims(const Geom &g);
+
 // ---- internal entry points (fp32) ----
 // wp : forward A operand in MFMA-fragment order, so a wave reads its 32x8 fragment with ONE fully
 //      coalesced 16-byte-per-lane load:
@@ -65,5 +78,16 @@ int pack_weights_f32(const Geom &g, const PackDims &pd, const float *weight, flo
                      hipStream_t stream);
 int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
                      hipStream_t stream);
+int build_tap_table_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *table,
+                        hipStream_t stream);
+int pack_gout_f32(const Geom &g, const BwdDims &bd, const float *gout, float *ga,
+                  hipStream_t stream);
+int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
+                        const int *table, float *part, hipStream_t stream);
+int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);
+int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
+                      float *gcol, hipStream_t stream);
+int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol, int *cnt,
+               int *rowptr, void *entries, hipStream_t stream);
 
 }  // namespace mdconv
