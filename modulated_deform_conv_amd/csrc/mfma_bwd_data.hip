@@ -12,15 +12,18 @@
 //     a lane owns ONE pixel and 32 channels, so grad_offset / grad_mask -- sums over channels of
 //     grad_col * d(sample) -- are reduced in registers, then across the two half-waves with one
 //     shuffle and across channel-waves through LDS, and written once per (tap, pixel) by their
-//     single owner.  grad_col itself is streamed to the workspace as [b][c][tap][pix] (the
-//     reference's grad_columns, per image) for step 3.
+//     single owner.  grad_col itself is streamed to the workspace CHANNEL-INNERMOST,
+//     [b][tap][pix][c] (16-byte stores: a lane holds 4 consecutive channels), for step 3.
 //  2. build_scatter_csr  (count -> scan -> fill, integer atomics only)
 //     inverts the scatter map: for every (image, tap, input pixel q) the list of
 //     (output pixel n, bilinear weight * mask) that land on q.  It depends only on offset / mask.
 //  3. col2im_gather_kernel
-//     grad_input[b][c][q] += sum over the lists of q of weight * grad_col[b][c][tap][n]:
-//     a gather (lanes = consecutive q, taps in lockstep so neighbours read neighbours),
-//     8 channels per list read, plain coalesced read-modify-write of grad_input.
+//     grad_input[b][c][q] += sum over the lists of q of weight * grad_col[b][tap][n][c]:
+//     one WAVE per input pixel q, lanes = channels (4 each), so every list entry is one
+//     wave-uniform scalar read plus one fully coalesced 16 B/lane vector read of all channels --
+//     no divergence, no atomics; a 32-pixel tile is transposed through LDS and added to the
+//     NCHW grad_input with whole-line accesses.  (A first version with lanes = pixels and
+//     per-lane list walks took 3.5 ms at cfg2; this one is HBM-bound.)
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
 
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_data_kernel(
         for (int a = 0; a < ND; ++a) dw[a][ci] = corner_dweight<ND, float>(tc, ci, a);
       }
     }
-    const int gc_voff = (((b_l * g.C + 4 * kh) * g.K + tap) * g.S_o + pix_l) * 4;
+    const int gc_voff = ((((b_l * g.K + tap) * g.S_o + pix_l) * g.C) + 4 * kh) * 4;
     float goff[ND], gm = 0.f;
 #pragma unroll
     for (int a = 0; a < ND; ++a) goff[a] = 0.f;
@@ -209,14 +212,20 @@ __global__ __launch_bounds__(256) void mfma_bwd_data_kernel(
 #pragma unroll
               for (int ci = 0; ci < NC; ++ci) v[rr][ci] = buf_load(r_in, voff[ci], cs);
             }
+            // grad_col[b][tap][pix][c]: rows r0+4g .. r0+4g+3 are 4 consecutive channels
+#pragma unroll
+            for (int gq = 0; gq < RB / 4; ++gq) {
+              const int cu4 = cbase + mb * 32 + 8 * ((r0 >> 2) + gq);
+              if (live && cu4 < g.C)
+                buf_store4(r_gc, gc_voff, cu4 * 4, acc[mb][r0 + 4 * gq], acc[mb][r0 + 4 * gq + 1],
+                           acc[mb][r0 + 4 * gq + 2], acc[mb][r0 + 4 * gq + 3]);
+            }
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) {
               const int r = r0 + rr;
               const int cu = cbase + mb * 32 + (r & 3) + 8 * (r >> 2);
               if (cu < g.C) {   // wave-uniform (C % 8 == 0)
                 const float gc = acc[mb][r];
-                if (live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gc), r_gc, gc_voff,
-                                                                cu * g.K * g.S_o * 4, 0);
                 float val = w[0] * v[rr][0];
 #pragma unroll
                 for (int ci = 1; ci < NC; ++ci) val = fmaf(w[ci], v[rr][ci], val);
@@ -344,47 +353,67 @@ __global__ __launch_bounds__(256) void csr_scan_kernel(int S_i, const int *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. grad_input[b][c][q] += sum_{tap} sum_{e in list(b, tap, q)} w_e * gcol[b][c][tap][n_e]
-// workgroup = 64 consecutive q x 4 channel groups; CH channels per list read.
+// 3. grad_input[b][c][q] += sum_{tap} sum_{e in list(b, tap, q)} w_e * gcol[b][tap][n_e][c]
+// workgroup = 32 consecutive q of one image x 256 channels; wave w walks q = q0 + w, w + 4, ...
 // ---------------------------------------------------------------------------------------------
-template <int ND, int CH>
+template <int ND>
 __global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float *__restrict__ gcol,
                                                             const int *__restrict__ rowptr,
                                                             const int2 *__restrict__ entries,
                                                             float *__restrict__ grad_input) {
   constexpr int NC = 1 << ND;
-  const int qtiles = (g.S_i + 63) / 64;
+  constexpr int QT = 32;
+  __shared__ float tile[256 * (QT + 1)];   // [c][q], pitch 33
+  const int qtiles = (g.S_i + QT - 1) / QT;
   const int b = blockIdx.x / qtiles;
-  const int q = (blockIdx.x - b * qtiles) * 64 + (threadIdx.x & 63);
-  const int cgrp = threadIdx.x >> 6;                 // 0..3
-  const bool live = q < g.S_i;
-  const int qq = live ? q : g.S_i - 1;
-  const int64_t plane = (int64_t)g.K * g.S_o;         // one channel of gcol
-  for (int c0 = blockIdx.y * (4 * CH) + cgrp * CH; c0 < g.C; c0 += gridDim.y * 4 * CH) {
-    float acc[CH];
+  const int q0 = (blockIdx.x - b * qtiles) * QT;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const rsrc_t r_gc = make_rsrc(gcol, (size_t)g.B * g.K * g.S_o * g.C * 4);
+  for (int cb = blockIdx.y * 256; cb < g.C; cb += gridDim.y * 256) {
+    const int c4 = cb + lane * 4;
+    const bool c_ok = c4 < g.C;   // C % 4 == 0
+    const int c_voff = (c_ok ? c4 : 0) * 4;
+    for (int qi = wave; qi < QT; qi += 4) {
+      const int q = q0 + qi;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < g.S_i) {
+        for (int tap = 0; tap < g.K; ++tap) {
+          const int seg = b * g.K + tap;
+          const int *rp = rowptr + (int64_t)seg * (g.S_i + 1) + q;
+          const int e0 = __builtin_amdgcn_readfirstlane(rp[0]);
+          const int e1 = __builtin_amdgcn_readfirstlane(rp[1]);
+          const int2 *ent = entries + (int64_t)seg * ((int64_t)g.S_o * NC);
+          const int soff_seg = seg * g.S_o;   // pixels
+          for (int e = e0; e < e1; ++e) {
+            const int2 en = ent[e];                                    // wave-uniform -> scalar load
+            const int n_e = __builtin_amdgcn_readfirstlane(en.x);
+            const float we = __int_as_float(__builtin_amdgcn_readfirstlane(en.y));
+            const float4 v = buf_load4(r_gc, c_voff, (soff_seg + n_e) * g.C * 4);
+            acc.x = fmaf(we, v.x, acc.x); acc.y = fmaf(we, v.y, acc.y);
+            acc.z = fmaf(we, v.z, acc.z); acc.w = fmaf(we, v.w, acc.w);
+          }
+        }
+      }
+      float *tp = tile + (lane * 4) * (QT + 1) + qi;
+      tp[0] = acc.x; tp[QT + 1] = acc.y; tp[2 * (QT + 1)] = acc.z; tp[3 * (QT + 1)] = acc.w;
+    }
+    __syncthreads();
+    // transpose out: thread = (channel, 8 consecutive q); a wave covers 8 channels x 32 q
+    {
+      const int cl = threadIdx.x >> 2, qs = (threadIdx.x & 3) * 8;
+      for (int cc = cl; cc < 256; cc += 64) {
+        const int c = cb + cc;
+        if (c < g.C) {
+          float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q0 + qs;
+          const float *src = tile + cc * (QT + 1) + qs;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) acc[i] = 0.f;
-    const float *gc = gcol + ((int64_t)b * g.C + c0) * plane;
-    for (int tap = 0; tap < g.K; ++tap) {
-      const int64_t seg = (int64_t)(b * g.K + tap);
-      const int *rp = rowptr + seg * (g.S_i + 1) + qq;
-      const int e0 = rp[0], e1 = live ? rp[1] : e0;
-      const int2 *ent = entries + seg * ((int64_t)g.S_o * NC);
-      const float *gt = gc + (int64_t)tap * g.S_o;
-      for (int e = e0; e < e1; ++e) {
-        const int2 en = ent[e];
-        const float we = __int_as_float(en.y);
-        const float *src = gt + en.x;
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-          if (c0 + i < g.C) acc[i] = fmaf(we, src[(int64_t)i * plane], acc[i]);
+          for (int k = 0; k < 8; ++k)
+            if (q0 + qs + k < g.S_i) dst[k] += src[k];
+        }
       }
     }
-    if (live) {
-#pragma unroll
-      for (int i = 0; i < CH; ++i)
-        if (c0 + i < g.C) grad_input[((int64_t)b * g.C + c0 + i) * g.S_i + q] += acc[i];
-    }
+    __syncthreads();
   }
 }
 
@@ -447,16 +476,13 @@ int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *
   if ((rc = check_launch("csr_fill"))) return rc;
 #undef LAUNCH_CSR2
 #undef LAUNCH_CSR
-  const int qtiles = (g.S_i + 63) / 64;
-  constexpr int CH = 8;
-  int cy = (g.C + 4 * CH - 1) / (4 * CH);
-  if (cy > 64) cy = 64;
-  const dim3 grid(g.B * qtiles, cy);
+  const int qtiles = (g.S_i + 31) / 32;
+  const dim3 grid(g.B * qtiles, 1);
   if (g.nd == 2)
-    hipLaunchKernelGGL((col2im_gather_kernel<2, CH>), grid, dim3(256), 0, stream, g, gcol, rowptr,
+    hipLaunchKernelGGL((col2im_gather_kernel<2>), grid, dim3(256), 0, stream, g, gcol, rowptr,
                        (const int2 *)entries, (float *)t.grad_input);
   else
-    hipLaunchKernelGGL((col2im_gather_kernel<3, CH>), grid, dim3(256), 0, stream, g, gcol, rowptr,
+    hipLaunchKernelGGL((col2im_gather_kernel<3>), grid, dim3(256), 0, stream, g, gcol, rowptr,
                        (const int2 *)entries, (float *)t.grad_input);
   (void)bd;
   return check_launch("col2im_gather");

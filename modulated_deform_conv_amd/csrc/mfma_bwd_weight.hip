@@ -257,12 +257,13 @@ __global__ __launch_bounds__(256) void reduce_weight_kernel(Geom g, BwdDims bd,
 }
 
 // grad_bias[o] += sum_{b, pix} grad_out[b][o][pix]   (mdeformable_conv.cu:440-444)
+// grid (O, image slices): a few thousand integer-free float atomics in total.
 __global__ __launch_bounds__(256) void grad_bias_kernel(Geom g, const float *__restrict__ gout,
                                                         float *__restrict__ grad_bias) {
   __shared__ float red[4];
   const int o = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < g.B; ++b) {
+  for (int b = blockIdx.y; b < g.B; b += gridDim.y) {
     const float *row = gout + (int64_t)(b * g.O + o) * g.S_o;
     for (int i = threadIdx.x; i < g.S_o; i += 256) s += row[i];
   }
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void grad_bias_kernel(Geom g, const float *__r
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) grad_bias[o] += red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) atomic_add(grad_bias + o, red[0] + red[1] + red[2] + red[3]);
 }
 
 int grid_for(int64_t total) {
@@ -317,7 +318,7 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
                      stream, g, bd, part, (float *)t.grad_weight);
   if ((rc = check_launch("reduce_weight"))) return rc;
   if (g.with_bias) {
-    hipLaunchKernelGGL(grad_bias_kernel, dim3(g.O), dim3(256), 0, stream, g,
+    hipLaunchKernelGGL(grad_bias_kernel, dim3(g.O, g.B < 16 ? g.B : 16), dim3(256), 0, stream, g,
                        (const float *)t.grad_output, (float *)t.grad_bias);
     rc = check_launch("grad_bias");
   }

@@ -49,8 +49,17 @@ __device__ __forceinline__ float4 buf_load4(rsrc_t r, int voff, int soff) {
   // The builtin returns an opaque 128-bit value: assigning it to an int4 vector SPLATS it
   // (every component = the first dword, and hipcc then narrows the load to one dword), so
   // reinterpret the bits through a struct instead.
+  // (its type is a GCC-style vector of 4 unsigned; bit_cast is the safe way out)
   const F4bits f = __builtin_bit_cast(F4bits, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
   return make_float4(f.x, f.y, f.z, f.w);
+}
+
+__device__ __forceinline__ void buf_store4(rsrc_t r, int voff, int soff, float a, float b, float c,
+                                           float d) {
+  typedef unsigned int u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+  const u32x4 v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                   __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
 }
 
 // Dimensions / workspace layout of the MFMA backward (fp32, groups == 1).
