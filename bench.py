@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json `metric`).
+
+A step = one forward + one backward of ModulatedDeformConv2d 3x3, C_in = C_out = 256, 56x56,
+B = 32 per GPU, fp32 (BASELINE.json configs[1]) on synthetic inputs already resident in HBM,
+through the MDCONV_CUDA surface (ctypes -> C ABI -> HIP kernels).  With N > 1 GPUs every rank
+runs its own 32-image shard (weak scaling) and the step ends with the one exchange the path has:
+the fused [grad_weight || grad_bias] all-reduce over RCCL.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# cfg2 of BASELINE.json
+B, C, O, H, W, KH, KW = 32, 256, 256, 56, 56, 3, 3
+K = KH * KW
+N_SAMPLES = B * C * K * H * W                      # 231 211 008 "samples" per GPU per step
+GEMM_FLOP = 2.0 * O * C * K * B * H * W            # one of the three GEMMs (118.4 GFLOP)
+PEAK_F32_MFMA_TFLOPS = 157.3                       # MI355X_MICROARCH.md, dense fp32 matrix peak
+# compulsory HBM bytes of one fwd+bwd step
+COMPULSORY_BYTES = 553_396_224
+HBM_PEAK_GBS = 8000.0
+
+
+def make_inputs(device, batch=B):
+    g = torch.Generator(device="cpu").manual_seed(0)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    x = rn(batch, C, H, W)
+    off = rn(batch, 2 * K, H, W)
+    m = torch.sigmoid(rn(batch, K, H, W))
+    w = (torch.rand(O, C, KH, KW, generator=g) * 2 - 1) / math.sqrt(C * K)
+    b = 0.1 * rn(O)
+    go = rn(batch, O, H, W)
+    return [t.to(device).contiguous() for t in (x, off, m, w, b, go)]
+
+
+def cpu_baseline(batch=2):
+    """The oracle (CPU restatement of the reference, kind = "port") on a bounded sample of the
+    same workload: cfg2 at B = `batch`, one forward + backward, all host threads OpenMP gives it."""
+    import oracle
+    oracle.build()
+    x, off, m, w, b, go = make_inputs("cpu", batch)
+    t0 = time.perf_counter()
+    oracle.forward(oracle.MDCN2D, x, w, b, off, m, 1, 1, 1, 1, 1, 64)
+    oracle.backward(oracle.MDCN2D, x, w, b, off, m, go, 1, 1, 1, 1, 1, 64)
+    dt = time.perf_counter() - t0
+    return {"value": batch * C * K * H * W / dt / 1e9, "unit": "GSamples/s",
+            "cores": oracle.num_threads(), "kind": "port",
+            "sample": "cfg2 shape at B=%d, 1 fwd+bwd, %.1f s" % (batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from modulated_deform_conv_amd import MDCONV_CUDA as M, _capi
+    from modulated_deform_conv_amd.distributed import FusedGradAllReduce
+    x, off, m, w, b, go = make_inputs(device)
+    geo = (KH, KW, 1, 1, 1, 1, 1, 1, 1, 1, 64, True)
+    reducer = FusedGradAllReduce() if distributed else None
+
+    def step():
+        out = M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo)
+        gi, goff, gm, gw, gb = M.modulated_deform_conv2d_backward_cuda(x, w, b, off, m, go, *geo)
+        if reducer is not None:
+            reducer(gw, gb)
+        return out, gi
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    paths = _capi.last_path()
+    _capi.profile_enable(True)
+    _capi.profile_reset()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _capi.profile_enable(False)
+    prof = _capi.profile_read()
+
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    if rank != 0:
+        if distributed:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = N_SAMPLES * world / (elapsed / args.steps) / 1e9
+    # dominant kernel = the MFMA GEMM kernel with the largest measured average duration
+    dom, (dom_n, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+    achieved = GEMM_FLOP / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    result = {
+        "metric": "fwd+bwd GSamples/s, MDCN2d 3x3 C=256 56x56 B=32; %HBM roofline",
+        "value": round(value, 3), "unit": "GSamples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ModulatedDeformConv2d 3x3, C_in=C_out=256, 56x56, B=32 per GPU, "
+                               "deformable_group=1, fp32, forward+backward (BASELINE.json configs[1])",
+                   "global_batch": B * world, "parallelism": "dp%d batch-sharded" % world,
+                   "kernel_path": paths},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2),
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "flop_per_launch": GEMM_FLOP, "avg_ms": round(dom_ms, 4), "launches": dom_n},
+        "kernels_ms": {k: round(v[1], 4) for k, v in prof.items()},
+        "hbm_roofline": {"compulsory_bytes": COMPULSORY_BYTES,
+                         "achieved_GBs": round(COMPULSORY_BYTES / (ms_per_step * 1e-3) / 1e9, 1),
+                         "peak_GBs": HBM_PEAK_GBS,
+                         "frac": round(COMPULSORY_BYTES / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

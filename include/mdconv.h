@@ -88,6 +88,14 @@ int mdconv_set_path(int path);
 /* Path the last forward / backward call of this thread actually ran (MDCONV_PATH_DIRECT/MFMA). */
 int mdconv_last_path(void);
 
+/* Per-kernel timing for benchmarks: when enabled, the three MFMA GEMM kernels are bracketed by HIP
+ * events ON THE CALLER'S STREAM.  After a stream/device synchronise, mdconv_profile_read() returns
+ * the number of launches of kernel `which` (0 = forward GEMM, 1 = backward data GEMM,
+ * 2 = backward weight GEMM) recorded since the last reset and their total duration in ms. */
+int mdconv_profile_enable(int on);
+int mdconv_profile_read(int which, double *total_ms);
+void mdconv_profile_reset(void);
+
 /* --- replaces deform_conv2d_forward_cuda (deformable_conv.cu:117-123) ---------------------- */
 int mdconv_deform_conv2d_forward(const mdconv_desc *d, const void *input, const void *weight,
                                  const void *bias, const void *offset, void *output,

@@ -15,6 +15,7 @@ PATH_AUTO, PATH_DIRECT, PATH_MFMA = 0, 1, 2
 EXPORTS = (
     "mdconv_abi_version", "mdconv_last_error", "mdconv_out_size", "mdconv_workspace_bytes",
     "mdconv_set_path", "mdconv_last_path",
+    "mdconv_profile_enable", "mdconv_profile_read", "mdconv_profile_reset",
     "mdconv_deform_conv2d_forward", "mdconv_deform_conv2d_backward",
     "mdconv_modulated_deform_conv2d_forward", "mdconv_modulated_deform_conv2d_backward",
     "mdconv_deform_conv3d_forward", "mdconv_deform_conv3d_backward",
@@ -51,7 +52,10 @@ def lib():
         L.mdconv_set_path.restype = ctypes.c_int
         L.mdconv_set_path.argtypes = [ctypes.c_int]
         L.mdconv_last_path.restype = ctypes.c_int
-        for name in EXPORTS[6:]:
+        L.mdconv_profile_enable.restype = ctypes.c_int
+        L.mdconv_profile_read.restype = ctypes.c_int
+        L.mdconv_profile_reset.restype = None
+        for name in EXPORTS[9:]:
             getattr(L, name).restype = ctypes.c_int
         if L.mdconv_abi_version() != 1:
             raise ImportError("libmdconv_hip.so ABI version mismatch")
@@ -72,3 +76,24 @@ def set_path(path):
 
 def last_path():
     return {0: "none", PATH_DIRECT: "direct", PATH_MFMA: "mfma"}[lib().mdconv_last_path()]
+
+
+PROFILE_KERNELS = {0: "mfma_fwd_kernel", 1: "mfma_bwd_data_kernel", 2: "mfma_bwd_weight_kernel"}
+
+
+def profile_enable(on=True):
+    return bool(lib().mdconv_profile_enable(int(on)))
+
+
+def profile_reset():
+    lib().mdconv_profile_reset()
+
+
+def profile_read():
+    """{kernel name: (launches, average ms)} -- call after torch.cuda.synchronize()."""
+    out = {}
+    for which, name in PROFILE_KERNELS.items():
+        tot = ctypes.c_double(0)
+        n = lib().mdconv_profile_read(which, ctypes.byref(tot))
+        out[name] = (n, tot.value / n if n else 0.0)
+    return out

@@ -306,12 +306,14 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
                         const int *table, float *part, hipStream_t stream) {
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
   const bool padn = bd.Np != g.N;
+  profile_mark(2, true, stream);
 #define LAUNCH_BW(ND, PADN)                                                                    \
   hipLaunchKernelGGL((mfma_bwd_weight_kernel<ND, PADN>), grid, dim3(256), 0, stream, g, bd,      \
                      (const float *)t.input, ga, table, part)
   if (g.nd == 2) { if (padn) LAUNCH_BW(2, true); else LAUNCH_BW(2, false); }
   else { if (padn) LAUNCH_BW(3, true); else LAUNCH_BW(3, false); }
 #undef LAUNCH_BW
+  profile_mark(2, false, stream);
   int rc = check_launch("mfma_bwd_weight");
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_weight_kernel, dim3(grid_for((int64_t)g.K * g.O * g.C)), dim3(256), 0,

@@ -2,9 +2,16 @@
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
 
+#include <vector>
+
 namespace mdconv {
 
 namespace {
+
+bool g_prof_on = false;
+struct ProfPair { hipEvent_t a, b; };
+std::vector<ProfPair> g_prof[3];
+size_t g_prof_used[3] = {0, 0, 0};
 
 // W[g*Og + o][c][tap]  ->  wp (MFMA-fragment order, mfma_tile.hpp) and wq[g][tap][o][c], zero padded.
 __global__ __launch_bounds__(256) void pack_weights_kernel(Geom g, PackDims pd,
@@ -35,6 +42,21 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(Geom g, PackDims pd,
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
+
+void profile_mark(int which, bool begin, hipStream_t stream) {
+  if (!g_prof_on || which < 0 || which > 2) return;
+  if (begin) {
+    if (g_prof_used[which] == g_prof[which].size()) {
+      ProfPair p;
+      if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+      g_prof[which].push_back(p);
+    }
+    (void)hipEventRecord(g_prof[which][g_prof_used[which]].a, stream);
+  } else if (g_prof_used[which] < g_prof[which].size()) {
+    (void)hipEventRecord(g_prof[which][g_prof_used[which]].b, stream);
+    ++g_prof_used[which];
+  }
+}
 
 int pack_weights_f32(const Geom &g, const PackDims &pd, const float *weight, float *wp, float *wq,
                      hipStream_t stream) {
@@ -104,7 +126,10 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
   float *wp = (float *)ws;
   int rc = pack_weights_f32(g, pd, (const float *)t.weight, wp, nullptr, stream);
   if (rc) return rc;
-  return mfma_forward_f32(g, pd, t, wp, stream);
+  profile_mark(0, true, stream);
+  rc = mfma_forward_f32(g, pd, t, wp, stream);
+  profile_mark(0, false, stream);
+  return rc;
 }
 
 int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
@@ -119,7 +144,10 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
   (void)dtype;
   // grad_offset / grad_mask (+ grad_col), then grad_input through the inverted scatter map
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
-  if ((rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, stream))) return rc;
+  profile_mark(1, true, stream);
+  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, stream);
+  profile_mark(1, false, stream);
+  if (rc) return rc;
   if ((rc = col2im_f32(g, bd, t, gcol, (int *)(base + bd.off_cnt), (int *)(base + bd.off_rowptr),
                        base + bd.off_entries, stream)))
     return rc;
@@ -129,4 +157,30 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
   return mfma_bwd_weight_f32(g, bd, t, ga, table, part, stream);
 }
 
+
 }  // namespace mdconv
+
+extern "C" {
+int mdconv_profile_enable(int on) {
+  const int prev = mdconv::g_prof_on ? 1 : 0;
+  mdconv::g_prof_on = on != 0;
+  return prev;
+}
+void mdconv_profile_reset(void) {
+  for (int i = 0; i < 3; ++i) mdconv::g_prof_used[i] = 0;
+}
+int mdconv_profile_read(int which, double *total_ms) {
+  if (which < 0 || which > 2) return 0;
+  double tot = 0;
+  int n = 0;
+  for (size_t i = 0; i < mdconv::g_prof_used[which]; ++i) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, mdconv::g_prof[which][i].a, mdconv::g_prof[which][i].b) == hipSuccess) {
+      tot += ms;
+      ++n;
+    }
+  }
+  if (total_ms) *total_ms = tot;
+  return n;
+}
+}

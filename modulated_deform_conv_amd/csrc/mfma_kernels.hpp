@@ -9,4 +9,7 @@ size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward);
 int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
 int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
 
+// benchmark hooks (include/mdconv.h: mdconv_profile_*)
+void profile_mark(int which, bool begin, hipStream_t stream);
+
 }  // namespace mdconv
