@@ -48,7 +48,22 @@ def make_inputs(device, batch=B):
     return [t.to(device).contiguous() for t in (x, off, m, w, b, go)]
 
 
-def cpu_baseline(batch=2):
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary
+    (profiles/rNN*_pmc_summary.json, produced by tools/summarize_profile.py); None if absent.
+    Counters cannot be collected inside this process, so the value is as old as that profile."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    for k, v in data.items():
+        if k.startswith(kernel):
+            return v["hbm_bytes_per_launch"], os.path.basename(files[-1])
+    return None, None
+
+
+def cpu_baseline(batch=16):
     """The oracle (CPU restatement of the reference, kind = "port") on a bounded sample of the
     same workload: cfg2 at B = `batch`, one forward + backward, all host threads OpenMP gives it."""
     import oracle
@@ -130,6 +145,7 @@ def main():
     # dominant kernel = the MFMA GEMM kernel with the largest measured average duration
     dom, (dom_n, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1])
     achieved = GEMM_FLOP / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    traffic, traffic_src = measured_traffic(dom)
     result = {
         "metric": "fwd+bwd GSamples/s, MDCN2d 3x3 C=256 56x56 B=32; %HBM roofline",
         "value": round(value, 3), "unit": "GSamples/s", "n_gpus": world, "steps": args.steps,
@@ -141,7 +157,8 @@ def main():
                    "kernel_path": paths},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "flop_per_launch": GEMM_FLOP, "avg_ms": round(dom_ms, 4), "launches": dom_n},
         "kernels_ms": {k: round(v[1], 4) for k, v in prof.items()},
         "hbm_roofline": {"compulsory_bytes": COMPULSORY_BYTES,
