@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
 // 1. GEMM-1 + coordinate gradients + grad_col stream
 // ---------------------------------------------------------------------------------------------
 template <int ND, bool MOD, int WAVES_C>
-__global__ __launch_bounds__(256) void mfma_bwd_data_kernel(
+__global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
@@ -75,12 +75,15 @@ __global__ __launch_bounds__(256) void mfma_bwd_data_kernel(
   constexpr int WAVES_P = 4 / WAVES_C;
   constexpr int BNP = 32 * WAVES_P;        // pixels per workgroup
   constexpr int BPT = BK * BNP / 256;      // grad_out elements per thread per chunk
-  constexpr int RB = 8;                    // accumulator rows gathered per batch
+  constexpr int RB = 32 / NC;              // accumulator rows gathered per batch (32 loads)
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * BNP];
 
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int n0 = tile * BNP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
+  // wave id as an SGPR: anything derived from threadIdx is 'divergent' to hipcc, and a divergent
+  // buffer soffset is wrapped in a readfirstlane waterfall per load (cdna_hip_programming.md T20)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WAVES_P, wp = wave % WAVES_P;
 
   // the pixel this lane owns in the accumulator layout
@@ -134,9 +137,13 @@ __global__ __launch_bounds__(256) void mfma_bwd_data_kernel(
       }
     }
     const int gc_voff = ((((b_l * g.K + tap) * g.S_o + pix_l) * g.C) + 4 * kh) * 4;
-    float goff[ND], gm = 0.f;
+    // S[ci] = sum over this lane's channels of grad_col * corner value.  The corner weights and
+    // their derivatives do not depend on the channel, so the epilogue costs 2^ND FMAs per channel
+    // and grad_mask / grad_offset are recovered from S once per tap:
+    //   grad_mask += sum_ci w[ci] S[ci],   grad_offset_a += m * sum_ci dw[a][ci] S[ci].
+    float S[NC];
 #pragma unroll
-    for (int a = 0; a < ND; ++a) goff[a] = 0.f;
+    for (int ci = 0; ci < NC; ++ci) S[ci] = 0.f;
 
     for (int pass = 0; pass < passes; ++pass) {
       const int cbase = (pass * WAVES_C + wc) * 64;       // this wave's 64 channels
@@ -198,51 +205,65 @@ __global__ __launch_bounds__(256) void mfma_bwd_data_kernel(
       }
 
       // ---- epilogue of (tap, pass): lane = pixel, acc rows = channels ----
+      // Rows are processed in batches of RB; the corner gathers of batch k+1 are in flight while
+      // batch k is consumed (sched_barriers keep hipcc from hoisting every gather to the top,
+      // which cost 284 VGPRs and occupancy 1).
       if (cbase < g.C) {
+        constexpr int NBATCH = MB * 16 / RB;
+        float v[2][RB][NC];
+        auto gather_batch = [&](float (&vb)[RB][NC], int k) {
+          const int mb = (k * RB) / 16, r0 = (k * RB) % 16;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+          for (int rr = 0; rr < RB; ++rr) {
+            const int r = r0 + rr;
+            const int cu = cbase + mb * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh is in the voffset
+            const int cs = min(cu, g.C - 5) * g.S_i * 4;   // cu % 8 < 4, so C-5 is the last valid one
 #pragma unroll
-          for (int r0 = 0; r0 < 16; r0 += RB) {
-            float v[RB][NC];
-#pragma unroll
-            for (int rr = 0; rr < RB; ++rr) {
-              const int r = r0 + rr;
-              const int cu = cbase + mb * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh is in the voffset
-              const int cs = min(cu, g.C - 5) * g.S_i * 4;   // cu % 8 < 4, so C-5 is the last valid one
-#pragma unroll
-              for (int ci = 0; ci < NC; ++ci) v[rr][ci] = buf_load(r_in, voff[ci], cs);
-            }
-            // grad_col[b][tap][pix][c]: rows r0+4g .. r0+4g+3 are 4 consecutive channels
-#pragma unroll
-            for (int gq = 0; gq < RB / 4; ++gq) {
-              const int cu4 = cbase + mb * 32 + 8 * ((r0 >> 2) + gq);
-              if (live && cu4 < g.C)
-                buf_store4(r_gc, gc_voff, cu4 * 4, acc[mb][r0 + 4 * gq], acc[mb][r0 + 4 * gq + 1],
-                           acc[mb][r0 + 4 * gq + 2], acc[mb][r0 + 4 * gq + 3]);
-            }
-#pragma unroll
-            for (int rr = 0; rr < RB; ++rr) {
-              const int r = r0 + rr;
-              const int cu = cbase + mb * 32 + (r & 3) + 8 * (r >> 2);
-              if (cu < g.C) {   // wave-uniform (C % 8 == 0)
-                const float gc = acc[mb][r];
-                float val = w[0] * v[rr][0];
-#pragma unroll
-                for (int ci = 1; ci < NC; ++ci) val = fmaf(w[ci], v[rr][ci], val);
-                gm = fmaf(gc, val, gm);
-#pragma unroll
-                for (int a = 0; a < ND; ++a) {
-                  float dv = dw[a][0] * v[rr][0];
-#pragma unroll
-                  for (int ci = 1; ci < NC; ++ci) dv = fmaf(dw[a][ci], v[rr][ci], dv);
-                  goff[a] = fmaf(gc, dv, goff[a]);
-                }
-              }
-            }
+            for (int ci = 0; ci < NC; ++ci) vb[rr][ci] = buf_load(r_in, voff[ci], cs);
           }
+        };
+        gather_batch(v[0], 0);
+#pragma unroll
+        for (int k = 0; k < NBATCH; ++k) {
+          if (k + 1 < NBATCH) gather_batch(v[(k + 1) & 1], k + 1);
+          asm volatile("" ::: "memory");   // IR-level fence: later gathers must not be hoisted here
+          __builtin_amdgcn_sched_barrier(0);
+          const int mb = (k * RB) / 16, r0 = (k * RB) % 16;
+          // grad_col[b][tap][pix][c]: rows r0+4g .. r0+4g+3 are 4 consecutive channels.  No
+          // branches here (they would split the block and let hipcc sink the S updates below all
+          // four batches, keeping 128 gathered values live): dead lanes / padded channels store to
+          // an out-of-range offset, which the buffer bounds check drops.
+#pragma unroll
+          for (int gq = 0; gq < RB / 4; ++gq) {
+            const int cu4 = cbase + mb * 32 + 8 * ((r0 >> 2) + gq);
+            const int vo = (live && cu4 < g.C) ? gc_voff : (int)0x7ffffff0;
+            buf_store4(r_gc, vo, cu4 * 4, acc[mb][r0 + 4 * gq], acc[mb][r0 + 4 * gq + 1],
+                       acc[mb][r0 + 4 * gq + 2], acc[mb][r0 + 4 * gq + 3]);
+          }
+          // padded channels have grad_col == 0 exactly (zero weight rows), no predicate needed
+#pragma unroll
+          for (int rr = 0; rr < RB; ++rr) {
+            const float gc = acc[mb][r0 + rr];
+#pragma unroll
+            for (int ci = 0; ci < NC; ++ci) S[ci] = fmaf(gc, v[k & 1][rr][ci], S[ci]);
+          }
+#pragma unroll
+          for (int ci = 0; ci < NC; ++ci) asm volatile("" : "+v"(S[ci]));   // pin the updates here
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
 
+    float goff[ND], gm = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) gm = fmaf(w[ci], S[ci], gm);
+#pragma unroll
+    for (int a = 0; a < ND; ++a) {
+      goff[a] = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) goff[a] = fmaf(dw[a][ci], S[ci], goff[a]);
+    }
     // ---- reduce over channels: the two half-waves, then the WAVES_C channel-waves ----
 #pragma unroll
     for (int a = 0; a < ND; ++a) goff[a] += __shfl_xor(goff[a], 32, 64);

@@ -124,7 +124,10 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   const int c0 = cblk * 32;
   const int dg = min(c0, g.C - 1) / g.Cdg;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
+  // wave id as an SGPR: anything derived from threadIdx is 'divergent' to hipcc, and a divergent
+  // buffer soffset is wrapped in a readfirstlane waterfall per load (cdna_hip_programming.md T20)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kk = tid & 15, sub = tid >> 4;   // pixel within the chunk, channel within the tile
 
   const int pairs_total = bd.Np / 32;

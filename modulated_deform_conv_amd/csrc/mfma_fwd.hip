@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   const int n0 = tn * BN;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR (uniform to the compiler)
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int kh = lane >> 5;
 
