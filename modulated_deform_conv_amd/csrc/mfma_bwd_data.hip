@@ -15,8 +15,9 @@
 //     single owner.  grad_col itself is streamed to the workspace CHANNEL-INNERMOST,
 //     [b][tap][pix][c] (16-byte stores: a lane holds 4 consecutive channels), for step 3.
 //  2. build_scatter_csr  (count -> scan -> fill, integer atomics only)
-//     inverts the scatter map: for every (image, tap, input pixel q) the list of
-//     (output pixel n, bilinear weight * mask) that land on q.  It depends only on offset / mask.
+//     inverts the scatter map: for every (image, input pixel q) the list of
+//     (tap * S_o + output pixel, bilinear weight * mask) that land on q.  Depends only on
+//     offset / mask.
 //  3. col2im_gather_kernel
 //     grad_input[b][c][q] += sum over the lists of q of weight * grad_col[b][tap][n][c]:
 //     one WAVE per input pixel q, lanes = channels (4 each), so every list entry is one
@@ -324,17 +325,17 @@ __global__ __launch_bounds__(256) void csr_pass_kernel(Geom g, const float *__re
     TapCoef<ND, float> tc;
     make_tap<ND, float>(g, oc, tcd, delta, true, tc);
     const float m = MOD ? mask[((int64_t)b * g.K + tap) * g.S_o + pix] : 1.f;
-    const int64_t seg = (int64_t)(b * g.K + tap);
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) {
       const float wa = corner_weight_atom<ND, float>(tc, ci);   // validity folded in
       if (wa != 0.f) {
         const int q = corner_index<ND, float>(tc, ci);
         if (!FILL) {
-          atomicAdd(cnt_or_cursor + seg * g.S_i + q, 1);
+          atomicAdd(cnt_or_cursor + (int64_t)b * g.S_i + q, 1);
         } else {
-          const int pos = rowptr[seg * (g.S_i + 1) + q] + atomicAdd(cnt_or_cursor + seg * g.S_i + q, 1);
-          entries[seg * ((int64_t)g.S_o * NC) + pos] = make_int2(pix, __float_as_int(wa * m));
+          const int pos = rowptr[(int64_t)b * (g.S_i + 1) + q] + atomicAdd(cnt_or_cursor + (int64_t)b * g.S_i + q, 1);
+          entries[(int64_t)b * ((int64_t)g.K * g.S_o * NC) + pos] =
+              make_int2(tap * g.S_o + pix, __float_as_int(wa * m));
         }
       }
     }
@@ -374,8 +375,10 @@ __global__ __launch_bounds__(256) void csr_scan_kernel(int S_i, const int *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. grad_input[b][c][q] += sum_{tap} sum_{e in list(b, tap, q)} w_e * gcol[b][tap][n_e][c]
+// 3. grad_input[b][c][q] += sum_{e in list(b, q)} w_e * gcol[b][src_e][c],  src = tap * S_o + pix
 // workgroup = 32 consecutive q of one image x 256 channels; wave w walks q = q0 + w, w + 4, ...
+// The list of q is fetched by ONE coalesced vector load (lane i <- entry i) and broadcast with
+// readlane, so there is no dependent scalar-load chain per entry.
 // ---------------------------------------------------------------------------------------------
 template <int ND>
 __global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float *__restrict__ gcol,
@@ -386,33 +389,44 @@ __global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float 
   constexpr int QT = 32;
   __shared__ float tile[256 * (QT + 1)];   // [c][q], pitch 33
   const int qtiles = (g.S_i + QT - 1) / QT;
-  const int b = blockIdx.x / qtiles;
-  const int q0 = (blockIdx.x - b * qtiles) * QT;
+  // every grad_col row is read by up to 2^ND targets (q, q+1, q+W, ...): keep neighbouring q
+  // tiles on ONE XCD so those re-reads hit its L2 instead of HBM (3.7 GB -> ~1 GB at cfg2)
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = bid / qtiles;
+  const int q0 = (bid - b * qtiles) * QT;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const rsrc_t r_gc = make_rsrc(gcol, (size_t)g.B * g.K * g.S_o * g.C * 4);
+  const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * g.C, (size_t)g.K * g.S_o * g.C * 4);
+  const int *rp = rowptr + (int64_t)b * (g.S_i + 1);
+  const int2 *ent = entries + (int64_t)b * ((int64_t)g.K * g.S_o * NC);
   for (int cb = blockIdx.y * 256; cb < g.C; cb += gridDim.y * 256) {
     const int c4 = cb + lane * 4;
-    const bool c_ok = c4 < g.C;   // C % 4 == 0
-    const int c_voff = (c_ok ? c4 : 0) * 4;
+    const int c_voff = (c4 < g.C ? c4 : 0) * 4;   // C % 4 == 0
     for (int qi = wave; qi < QT; qi += 4) {
       const int q = q0 + qi;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (q < g.S_i) {
-        for (int tap = 0; tap < g.K; ++tap) {
-          const int seg = b * g.K + tap;
-          const int *rp = rowptr + (int64_t)seg * (g.S_i + 1) + q;
-          const int e0 = __builtin_amdgcn_readfirstlane(rp[0]);
-          const int e1 = __builtin_amdgcn_readfirstlane(rp[1]);
-          const int2 *ent = entries + (int64_t)seg * ((int64_t)g.S_o * NC);
-          const int soff_seg = seg * g.S_o;   // pixels
-          for (int e = e0; e < e1; ++e) {
-            const int2 en = ent[e];                                    // wave-uniform -> scalar load
-            const int n_e = __builtin_amdgcn_readfirstlane(en.x);
-            const float we = __int_as_float(__builtin_amdgcn_readfirstlane(en.y));
-            const float4 v = buf_load4(r_gc, c_voff, (soff_seg + n_e) * g.C * 4);
-            acc.x = fmaf(we, v.x, acc.x); acc.y = fmaf(we, v.y, acc.y);
-            acc.z = fmaf(we, v.z, acc.z); acc.w = fmaf(we, v.w, acc.w);
+        const int e0 = __builtin_amdgcn_readfirstlane(rp[q]);
+        const int e1 = __builtin_amdgcn_readfirstlane(rp[q + 1]);
+        for (int base = e0; base < e1; base += 64) {
+          const int cnt = min(64, e1 - base);
+          const int2 mine = (lane < cnt) ? ent[base + lane] : make_int2(0, 0);
+          // 16 independent row loads in flight per step (a one-entry-at-a-time loop serialises
+          // the full memory latency per entry: 0.65 ms at cfg2); lanes >= cnt hold weight 0, row 0
+          for (int i = 0; i < cnt; i += 16) {
+            float4 v[16];
+            float we[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int src = __builtin_amdgcn_readlane(mine.x, (i + u) & 63);
+              we[u] = __int_as_float(__builtin_amdgcn_readlane(mine.y, (i + u) & 63));
+              v[u] = buf_load4(r_gc, c_voff, src * g.C * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              acc.x = fmaf(we[u], v[u].x, acc.x); acc.y = fmaf(we[u], v[u].y, acc.y);
+              acc.z = fmaf(we[u], v[u].z, acc.z); acc.w = fmaf(we[u], v[u].w, acc.w);
+            }
           }
         }
       }
@@ -474,7 +488,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
 int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol, int *cnt,
                int *rowptr, void *entries, hipStream_t stream) {
   const int64_t samples = (int64_t)g.B * g.K * g.S_o;
-  const size_t cnt_bytes = (size_t)g.B * g.K * g.S_i * sizeof(int);
+  const size_t cnt_bytes = (size_t)g.B * g.S_i * sizeof(int);
   hipError_t e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
   if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
 #define LAUNCH_CSR(ND, MOD, FILL)                                                               \
@@ -489,7 +503,7 @@ int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *
   LAUNCH_CSR2(false);
   int rc = check_launch("csr_count");
   if (rc) return rc;
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B * g.K), dim3(256), 0, stream, g.S_i, cnt, rowptr);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B), dim3(256), 0, stream, g.S_i, cnt, rowptr);
   if ((rc = check_launch("csr_scan"))) return rc;
   e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
   if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }

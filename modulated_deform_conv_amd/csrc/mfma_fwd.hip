@@ -104,11 +104,9 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   float rg[CPT][NC];
   int cur_tap = -1, cur_dg = -1;
 
-  // request the gathers of chunk t (and rebuild the sampling state when (tap, dg) changes)
-  auto issue = [&](int t) {
-    const int tap = t / cchunks;
-    const int c0 = (t - tap * cchunks) * BK;
-    const int dg = min(grp * g.Cg + c0, g.C - 1) / g.Cdg;
+  // request the gathers of chunk (tap, c0) (and rebuild the sampling state when (tap, dg) changes)
+  auto issue = [&](int tap, int c0) {
+    const int dg = g.DG == 1 ? 0 : min(grp * g.Cg + c0, g.C - 1) / g.Cdg;
     if (tap != cur_tap || dg != cur_dg) {
       float delta[ND];
       const int64_t ob = ((int64_t)(b_g * g.DG + dg) * (ND * g.K) + ND * tap) * g.S_o + pix_g;
@@ -139,22 +137,21 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
 #endif
       }
   };
-  // interpolate the gathered corners and publish the B slab of chunk t
-  auto commit = [&](int t, float *Bb) {
+  // interpolate the gathered corners and publish the B slab of the chunk starting at channel c0
+  auto commit = [&](int c0, float *Bb) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       float val = wgt[0] * rg[i][0];
 #pragma unroll
       for (int ci = 1; ci < NC; ++ci) val = fmaf(wgt[ci], rg[i][ci], val);
       if (PADK) {   // ragged C_in/groups: rows of the padded K range must be exactly zero
-        const int tap = t / cchunks;
-        const int cl = (t - tap * cchunks) * BK + ksub * CPT + i;
+        const int cl = c0 + ksub * CPT + i;
         val = cl < g.Cg ? val : 0.f;
       }
       Bb[(ksub * CPT + i) * BN + j] = val;
     }
   };
-  auto load_a = [&](float4 (&ra)[MB][2], int t) {
+  auto load_a = [&](float4 (&ra)[MB][2], int soff) {   // soff = chunk index * slab_bytes
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -162,7 +159,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
 #ifdef ABL_NOWEIGHT
         ra[i][q] = make_float4(0.5f, 0.25f, 1.f, 2.f);
 #else
-        ra[i][q] = buf_load4(r_wp, a_voff + (i * 2 + q) * 1024, t * slab_bytes);
+        ra[i][q] = buf_load4(r_wp, a_voff + (i * 2 + q) * 1024, soff);
 #endif
       }
   };
@@ -189,32 +186,42 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       }
   };
 
-  // T is even (C_in/groups is padded to 2*BK with zero weights), so the 2x unrolled loop needs no
-  // tail and every prefetch is unconditional: with an `if (t + 1 < T)` around the requests hipcc
-  // lost track of the outstanding-load count and put s_waitcnt vmcnt(0) in front of the MFMAs.
+  // The chunk count per tap is even (C_in/groups is padded to 2*BK with zero weights), so the 2x
+  // unrolled loop needs no tail, a tap change can only happen after an odd chunk, and every
+  // prefetch is unconditional (with an `if (t + 1 < T)` around the requests hipcc lost track of
+  // the outstanding-load count and put s_waitcnt vmcnt(0) in front of the MFMAs).  Plain nested
+  // counters keep the per-chunk scalar work to a few SALU instructions (a flat chunk index cost
+  // ~50 SALU per chunk in integer divisions).
   float4 ra0[MB][2], ra1[MB][2];
+  const int a_last = (T - 1) * slab_bytes;
+  int a_soff = 0;   // byte offset of the current chunk in the packed weights
   load_a(ra0, 0);
-  issue(0);
-  for (int t = 0; t < T; t += 2) {
-    // ---- even chunk: LDS buffer 0, fragments ra0 ----
-    commit(t, Bs);
+  issue(0, 0);
+  for (int tap = 0; tap < g.K; ++tap) {
+    for (int c0 = 0; c0 < pd.Cgp; c0 += 2 * BK) {
+      // ---- even chunk: LDS buffer 0, fragments ra0 ----
+      commit(c0, Bs);
 #ifndef ABL_NOBARRIER
-    __syncthreads();
+      __syncthreads();
 #endif
-    issue(t + 1);
-    load_a(ra1, t + 1);
-    __builtin_amdgcn_sched_barrier(0);   // keep every request above the MFMA phase
-    mma(ra0, Bs);
-    // ---- odd chunk: LDS buffer 1, fragments ra1 ----
-    commit(t + 1, Bs + BK * BN);
+      issue(tap, c0 + BK);
+      load_a(ra1, a_soff + slab_bytes);
+      __builtin_amdgcn_sched_barrier(0);   // keep every request above the MFMA phase
+      mma(ra0, Bs);
+      // ---- odd chunk: LDS buffer 1, fragments ra1 ----
+      commit(c0 + BK, Bs + BK * BN);
 #ifndef ABL_NOBARRIER
-    __syncthreads();
+      __syncthreads();
 #endif
-    const int tn = min(t + 2, T - 1);    // past the end: re-request the last chunk, unused
-    issue(tn);
-    load_a(ra0, tn);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(ra1, Bs + BK * BN);
+      a_soff += 2 * slab_bytes;
+      const bool wrap = c0 + 2 * BK >= pd.Cgp;
+      const int ntap = wrap ? min(tap + 1, g.K - 1) : tap;   // past the end: harmless re-request
+      const int nc0 = wrap ? 0 : c0 + 2 * BK;
+      issue(ntap, nc0);
+      load_a(ra0, min(a_soff, a_last));
+      __builtin_amdgcn_sched_barrier(0);
+      mma(ra1, Bs + BK * BN);
+    }
   }
 
   // ---- epilogue: + bias, store [B, O, S_o] (lanes 0-31 -> 32 consecutive pixels) ----
