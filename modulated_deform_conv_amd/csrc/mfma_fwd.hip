@@ -22,9 +22,9 @@
 //     immediate): zero VALU, never touches LDS;
 //   * interpolation = 2^ND FMAs per sample; the B slab is written to a double-buffered k-major
 //     LDS tile (n across lanes, conflict-free) at lane-constant addresses;
-//   * the chunk loop is unrolled by two (LDS buffer parity and the A-fragment register set are
-//     compile-time), one barrier per chunk, requests for chunk t+1 are issued before the MFMAs
-//     of chunk t.
+//   * the chunk loop is unrolled by two (LDS buffer parity and the register sets are
+//     compile-time), one barrier per chunk; gathers are requested two chunks ahead, weight
+//     fragments one chunk ahead, always before the MFMAs of the current chunk.
 // B fragments are read with ds_read_b32: lanes 0-31 / 32-63 hit two different k rows, each 32
 // consecutive dwords -> no bank conflicts.
 #include "mfma_kernels.hpp"
@@ -99,13 +99,18 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
-  int voff[NC];     // corner byte offsets for the current (tap, dg)
-  float wgt[NC];    // corner weights * mask
-  float rg[CPT][NC];
+  // Gathers run TWO chunks ahead of the MFMAs (one chunk was not enough to cover the L2/MALL
+  // latency: the loads added 0.18 ms to an otherwise 0.97 ms kernel).  voff / wgt describe the
+  // (tap, dg) of the chunk being requested; each of the two in-flight register sets remembers
+  // the weights it was requested with.
+  int voff[NC];       // corner byte offsets of the chunk being requested
+  float wgt[NC];      // its corner weights * mask
+  float rg0[CPT][NC], rg1[CPT][NC];
+  float wc0[NC], wc1[NC];
   int cur_tap = -1, cur_dg = -1;
 
   // request the gathers of chunk (tap, c0) (and rebuild the sampling state when (tap, dg) changes)
-  auto issue = [&](int tap, int c0) {
+  auto issue = [&](float (&rg)[CPT][NC], float (&wc)[NC], int tap, int c0) {
     const int dg = g.DG == 1 ? 0 : min(grp * g.Cg + c0, g.C - 1) / g.Cdg;
     if (tap != cur_tap || dg != cur_dg) {
       float delta[ND];
@@ -136,14 +141,16 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
         rg[i][ci] = buf_load(r_in, voff[ci], soff + i * g.S_i * 4);
 #endif
       }
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) wc[ci] = wgt[ci];
   };
   // interpolate the gathered corners and publish the B slab of the chunk starting at channel c0
-  auto commit = [&](int c0, float *Bb) {
+  auto commit = [&](const float (&rg)[CPT][NC], const float (&wc)[NC], int c0, float *Bb) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      float val = wgt[0] * rg[i][0];
+      float val = wc[0] * rg[i][0];
 #pragma unroll
-      for (int ci = 1; ci < NC; ++ci) val = fmaf(wgt[ci], rg[i][ci], val);
+      for (int ci = 1; ci < NC; ++ci) val = fmaf(wc[ci], rg[i][ci], val);
       if (PADK) {   // ragged C_in/groups: rows of the padded K range must be exactly zero
         const int cl = c0 + ksub * CPT + i;
         val = cl < g.Cg ? val : 0.f;
@@ -196,28 +203,30 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   const int a_last = (T - 1) * slab_bytes;
   int a_soff = 0;   // byte offset of the current chunk in the packed weights
   load_a(ra0, 0);
-  issue(0, 0);
+  issue(rg0, wc0, 0, 0);
+  issue(rg1, wc1, 0, BK);
   for (int tap = 0; tap < g.K; ++tap) {
     for (int c0 = 0; c0 < pd.Cgp; c0 += 2 * BK) {
-      // ---- even chunk: LDS buffer 0, fragments ra0 ----
-      commit(c0, Bs);
+      // position of the chunk pair two chunks ahead (past the end: harmless re-request)
+      const bool wrap = c0 + 2 * BK >= pd.Cgp;
+      const int ntap = wrap ? min(tap + 1, g.K - 1) : tap;
+      const int nc0 = wrap ? 0 : c0 + 2 * BK;
+      // ---- even chunk: LDS buffer 0, fragments ra0, gathers rg0 ----
+      commit(rg0, wc0, c0, Bs);
 #ifndef ABL_NOBARRIER
       __syncthreads();
 #endif
-      issue(tap, c0 + BK);
+      issue(rg0, wc0, ntap, nc0);
       load_a(ra1, a_soff + slab_bytes);
       __builtin_amdgcn_sched_barrier(0);   // keep every request above the MFMA phase
       mma(ra0, Bs);
-      // ---- odd chunk: LDS buffer 1, fragments ra1 ----
-      commit(c0 + BK, Bs + BK * BN);
+      // ---- odd chunk: LDS buffer 1, fragments ra1, gathers rg1 ----
+      commit(rg1, wc1, c0 + BK, Bs + BK * BN);
 #ifndef ABL_NOBARRIER
       __syncthreads();
 #endif
       a_soff += 2 * slab_bytes;
-      const bool wrap = c0 + 2 * BK >= pd.Cgp;
-      const int ntap = wrap ? min(tap + 1, g.K - 1) : tap;   // past the end: harmless re-request
-      const int nc0 = wrap ? 0 : c0 + 2 * BK;
-      issue(ntap, nc0);
+      issue(rg1, wc1, ntap, nc0 + BK);
       load_a(ra0, min(a_soff, a_last));
       __builtin_amdgcn_sched_barrier(0);
       mma(ra1, Bs + BK * BN);

@@ -38,6 +38,9 @@ CASES = [
     _c("mdcn3d_basic", M3, 2, 4, 4, (4, 6, 5), 3, seed=14),
     _c("mdcn3d_dil2_dg2", M3, 2, 4, 8, (6, 7, 6), 3, padding=2, dilation=2, dgroups=2, in_step=1, seed=15),
     _c("mdcn3d_g2_big_offsets", M3, 2, 8, 4, (5, 5, 5), 3, groups=2, dgroups=4, seed=16, offset_scale=3.0),
+    # small but MFMA-eligible (>= 16 channels per group): the golden fixtures of the MFMA path
+    _c("mfma_mdcn2d_c32_o48_9x10", M2, 2, 32, 48, (9, 10), 3, in_step=1, seed=17),
+    _c("mfma_dcn3d_c16_o16_5x6x5", D3, 2, 16, 16, (5, 6, 5), 3, bias=False, seed=18),
     # medium: down-scaled analogues of BASELINE.json configs[1..4] (same K / stride / dilation /
     # G : DG structure, channel counts that exercise the MFMA tiles incl. ragged edges)
     _c("cfg2s_mdcn2d_c64_28x28_b4", M2, 4, 64, 64, (28, 28), 3, tier="medium", seed=21),
