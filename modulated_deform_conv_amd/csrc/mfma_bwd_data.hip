@@ -223,10 +223,19 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
             for (int ci = 0; ci < NC; ++ci) vb[rr][ci] = buf_load(r_in, voff[ci], cs);
           }
         };
+#ifdef ABL_SINGLEBUF
+#define VB(k) 0
+#else
+#define VB(k) ((k) & 1)
         gather_batch(v[0], 0);
+#endif
 #pragma unroll
         for (int k = 0; k < NBATCH; ++k) {
+#ifdef ABL_SINGLEBUF
+          gather_batch(v[0], k);
+#else
           if (k + 1 < NBATCH) gather_batch(v[(k + 1) & 1], k + 1);
+#endif
           asm volatile("" ::: "memory");   // IR-level fence: later gathers must not be hoisted here
           __builtin_amdgcn_sched_barrier(0);
           const int mb = (k * RB) / 16, r0 = (k * RB) % 16;
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
           for (int rr = 0; rr < RB; ++rr) {
             const float gc = acc[mb][r0 + rr];
 #pragma unroll
-            for (int ci = 0; ci < NC; ++ci) S[ci] = fmaf(gc, v[k & 1][rr][ci], S[ci]);
+            for (int ci = 0; ci < NC; ++ci) S[ci] = fmaf(gc, v[VB(k)][rr][ci], S[ci]);
           }
 #pragma unroll
           for (int ci = 0; ci < NC; ++ci) asm volatile("" : "+v"(S[ci]));   // pin the updates here

@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   const rsrc_t r_tab = make_rsrc(table + (size_t)(dg * g.K + tap) * bd.Np * (2 * NC),
                                  (size_t)bd.Np * entry_bytes);
   const int a_voff = ((mtile * 8 + wave * MB) * 2 * 64 + lane) * 16;
+  // rows of this wave beyond C_out are padding: skip their fragment loads and MFMAs (the wave
+  // still gathers and synchronises) -- with C_out = 64 this is 4x less matrix work
+  const bool m_active = mtile * 256 + wave * 64 < g.O;
   const int t_voff = kk * entry_bytes;
   const int chan_voff = (c0 + sub) * g.S_i * 4;   // this thread's first channel plane
   const int chan_soff = 16 * g.S_i * 4;           // its second channel is 16 planes further
@@ -184,12 +187,14 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
     }
   };
   auto load_a = [&](float4 (&ra)[MB][2], int t) {
+    if (!m_active) return;
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int q = 0; q < 2; ++q) ra[i][q] = buf_load4(r_ga, a_voff + (i * 2 + q) * 1024, t * slab_bytes);
   };
   auto mma = [&](const float4 (&ra)[MB][2], const float *Bbuf) {
+    if (!m_active) return;
     const float *Bb = Bbuf + (lane & 31) + 4 * kh * kPitch;
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   if (t_begin < t_end) {
     const int t_last = t_end - 1;
     Tab tabA, tabB;
-    float4 ra0[MB][2], ra1[MB][2];
+    float4 ra0[MB][2] = {}, ra1[MB][2] = {};
     load_tab(tabA, t_begin);
     load_tab(tabB, t_begin + 1);
     load_a(ra0, t_begin);
