@@ -69,6 +69,7 @@ template <int ND, typename A> struct TapCoef {
   A sh[ND];      // ... of the high side: +1 or 0
   int base;      // element index (inside one [S_i] plane) of the clamped low corner
   int delta[ND]; // index step low -> high per axis (0 when clamped)
+  int last_lc;   // clamped low coordinate on the last (contiguous) axis
   bool inside;   // -1 < p_a < size_a on every axis
 };
 
@@ -133,6 +134,7 @@ __device__ __forceinline__ void make_tap(const Geom &g, const int *o, const int 
     for (int a2 = a + 1; a2 < ND; ++a2) plane_stride *= g.in_sz[a2];
     idx += lc * plane_stride;
     tc.delta[a] = (hc - lc) * plane_stride;
+    if (a == ND - 1) tc.last_lc = lc;
   }
   tc.base = idx;
   tc.inside = inside;
@@ -171,6 +173,36 @@ __device__ __forceinline__ A corner_dweight(const TapCoef<ND, A> &tc, int ci, in
     w *= (a == axis) ? (hi ? tc.sh[a] : tc.sl[a]) : (hi ? tc.wh[a] : tc.wl[a]);
   }
   return w;
+}
+
+// Paired corners: the two neighbours along the last (contiguous) axis are fetched with ONE 8-byte
+// load from column cl = min(low, size-2), so a sample costs 2^(ND-1) gathers instead of 2^ND.
+// Pair pi (bit (ND-2-a) set <=> axis a high, a < ND-1) gets element index idx[pi] (of its first
+// element) and weights wx[pi] / wy[pi] for the two loaded values; clamped or out-of-image sides
+// are handled purely through the weights.  Needs size of the last axis >= 2.
+template <int ND, typename A>
+__device__ __forceinline__ void make_pairs(const Geom &g, const TapCoef<ND, A> &tc, A scale,
+                                           int (&idx)[1 << (ND - 1)], A (&wx)[1 << (ND - 1)],
+                                           A (&wy)[1 << (ND - 1)]) {
+  constexpr int L = ND - 1;
+  const int lc = tc.last_lc, hc = tc.last_lc + tc.delta[L];
+  const int cl = min(lc, g.in_sz[L] - 2);
+  const A xw = (lc == cl ? tc.wl[L] : (A)0) + (hc == cl ? tc.wh[L] : (A)0);
+  const A yw = (lc == cl + 1 ? tc.wl[L] : (A)0) + (hc == cl + 1 ? tc.wh[L] : (A)0);
+#pragma unroll
+  for (int pi = 0; pi < (1 << L); ++pi) {
+    int id = tc.base - lc + cl;
+    A w = scale;
+#pragma unroll
+    for (int a = 0; a < L; ++a) {
+      const bool hi = (pi >> (L - 1 - a)) & 1;
+      id += hi ? tc.delta[a] : 0;
+      w *= hi ? tc.wh[a] : tc.wl[a];
+    }
+    idx[pi] = id;
+    wx[pi] = w * xw;
+    wy[pi] = w * yw;
+  }
 }
 
 // ---- host-side helpers ------------------------------------------------------------------------

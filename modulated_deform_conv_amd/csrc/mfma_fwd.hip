@@ -15,8 +15,10 @@
 //     builds the sampling state ONCE: 2^ND corner byte-offsets (image / channel-subset base
 //     folded in) and 2^ND corner weights (validity and the mask folded in) -- offset/mask are
 //     read K times per tile, not C*K times;
-//   * gathers are raw buffer loads `buffer_load_dword v, voff[corner], rsrc(input), soffset`:
-//     the per-chunk channel base lives in the SGPR soffset, so a gather costs zero VALU;
+//   * gathers are raw buffer loads `buffer_load_dwordx2 v, voff[pair], rsrc(input), soffset`:
+//     the two corners that are neighbours along the contiguous axis come with one 8-byte load
+//     (make_pairs), and the per-chunk channel base lives in the SGPR soffset, so a gather
+//     costs zero VALU;
 //   * the weight operand is pre-packed in MFMA-fragment order (mfma_tile.hpp) and fetched with
 //     buffer_load_dwordx4 (lane-constant voffset, chunk base in soffset, fragment index in the
 //     immediate): zero VALU, never touches LDS;
@@ -48,6 +50,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
                                                        float *__restrict__ output, int ntm, int ntn) {
   constexpr int BK = kBK;
   constexpr int NC = 1 << ND;
+  constexpr int NP = NC / 2;                  // corner pairs along the contiguous axis
   constexpr int MB = WM / 32, NB = WN / 32;   // 32x32 MFMA blocks per wave
   constexpr int WAVES_N = BN / WN;
   constexpr int KSUBS = 256 / BN;             // k-subsets of the B-slab generation
@@ -103,14 +106,14 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   // latency: the loads added 0.18 ms to an otherwise 0.97 ms kernel).  voff / wgt describe the
   // (tap, dg) of the chunk being requested; each of the two in-flight register sets remembers
   // the weights it was requested with.
-  int voff[NC];       // corner byte offsets of the chunk being requested
-  float wgt[NC];      // its corner weights * mask
-  float rg0[CPT][NC], rg1[CPT][NC];
+  int voff[NP];       // byte offsets of the corner PAIRS of the chunk being requested
+  float wgt[NC];      // their weights * mask: [2*pi] first element, [2*pi+1] second
+  float2 rg0[CPT][NP], rg1[CPT][NP];
   float wc0[NC], wc1[NC];
   int cur_tap = -1, cur_dg = -1;
 
   // request the gathers of chunk (tap, c0) (and rebuild the sampling state when (tap, dg) changes)
-  auto issue = [&](float (&rg)[CPT][NC], float (&wc)[NC], int tap, int c0) {
+  auto issue = [&](float2 (&rg)[CPT][NP], float (&wc)[NC], int tap, int c0) {
     const int dg = g.DG == 1 ? 0 : min(grp * g.Cg + c0, g.C - 1) / g.Cdg;
     if (tap != cur_tap || dg != cur_dg) {
       float delta[ND];
@@ -122,10 +125,14 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       TapCoef<ND, float> tc;
       make_tap<ND, float>(g, oc, tcd, delta, false, tc);
       const float m = MOD ? mask[((int64_t)(b_g * g.DG + dg) * g.K + tap) * g.S_o + pix_g] : 1.f;
+      int pidx[NP];
+      float pwx[NP], pwy[NP];
+      make_pairs<ND, float>(g, tc, m, pidx, pwx, pwy);
 #pragma unroll
-      for (int ci = 0; ci < NC; ++ci) {
-        voff[ci] = img_voff + corner_index<ND, float>(tc, ci) * 4;
-        wgt[ci] = corner_weight<ND, float>(tc, ci) * m;
+      for (int pi = 0; pi < NP; ++pi) {
+        voff[pi] = img_voff + pidx[pi] * 4;
+        wgt[2 * pi] = pwx[pi];
+        wgt[2 * pi + 1] = pwy[pi];
       }
       cur_tap = tap;
       cur_dg = dg;
@@ -134,23 +141,27 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
 #pragma unroll
     for (int i = 0; i < CPT; ++i)
 #pragma unroll
-      for (int ci = 0; ci < NC; ++ci) {
+      for (int pi = 0; pi < NP; ++pi) {
 #ifdef ABL_NOGATHER
-        rg[i][ci] = (float)(voff[ci] + soff);
+        rg[i][pi] = make_float2((float)(voff[pi] + soff), 1.f);
 #else
-        rg[i][ci] = buf_load(r_in, voff[ci], soff + i * g.S_i * 4);
+        rg[i][pi] = buf_load2(r_in, voff[pi], soff + i * g.S_i * 4);
 #endif
       }
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) wc[ci] = wgt[ci];
   };
   // interpolate the gathered corners and publish the B slab of the chunk starting at channel c0
-  auto commit = [&](const float (&rg)[CPT][NC], const float (&wc)[NC], int c0, float *Bb) {
+  auto commit = [&](const float2 (&rg)[CPT][NP], const float (&wc)[NC], int c0, float *Bb) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      float val = wc[0] * rg[i][0];
+      float val = wc[0] * rg[i][0].x;
+      val = fmaf(wc[1], rg[i][0].y, val);
 #pragma unroll
-      for (int ci = 1; ci < NC; ++ci) val = fmaf(wc[ci], rg[i][ci], val);
+      for (int pi = 1; pi < NP; ++pi) {
+        val = fmaf(wc[2 * pi], rg[i][pi].x, val);
+        val = fmaf(wc[2 * pi + 1], rg[i][pi].y, val);
+      }
       if (PADK) {   // ragged C_in/groups: rows of the padded K range must be exactly zero
         const int cl = c0 + ksub * CPT + i;
         val = cl < g.Cg ? val : 0.f;

@@ -102,6 +102,7 @@ BwdDims bwd_dims(const Geom &g) {
 bool mfma_supported(const Geom &g, int dtype, bool backward) {
   if (dtype != MDCONV_F32) return false;
   if (g.Cg < 16 || g.Og < 16) return false;  // MFMA tiles would be mostly padding
+  if (g.in_sz[g.nd - 1] < 2) return false;   // paired-corner gathers need 2 columns
   if (!(g.DG == 1 || (g.Cdg % (2 * kBK) == 0 && g.Cg % (2 * kBK) == 0))) return false;
   // raw buffer addressing: every tensor must stay below 2 GiB
   if ((size_t)g.B * g.C * g.S_i * sizeof(float) >= ((size_t)1 << 31)) return false;

@@ -44,6 +44,11 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, size_t bytes) {
 __device__ __forceinline__ float buf_load(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+struct F2bits { float x, y; };
+__device__ __forceinline__ float2 buf_load2(rsrc_t r, int voff, int soff) {
+  const F2bits f = __builtin_bit_cast(F2bits, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+  return make_float2(f.x, f.y);
+}
 struct F4bits { float x, y, z, w; };
 __device__ __forceinline__ float4 buf_load4(rsrc_t r, int voff, int soff) {
   // The builtin returns an opaque 128-bit value: assigning it to an int4 vector SPLATS it
