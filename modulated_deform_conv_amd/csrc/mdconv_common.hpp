@@ -181,14 +181,15 @@ __device__ __forceinline__ A corner_dweight(const TapCoef<ND, A> &tc, int ci, in
 // element) and weights wx[pi] / wy[pi] for the two loaded values; clamped or out-of-image sides
 // are handled purely through the weights.  Needs size of the last axis >= 2.
 template <int ND, typename A>
-__device__ __forceinline__ void make_pairs(const Geom &g, const TapCoef<ND, A> &tc, A scale,
-                                           int (&idx)[1 << (ND - 1)], A (&wx)[1 << (ND - 1)],
-                                           A (&wy)[1 << (ND - 1)]) {
+__device__ __forceinline__ void make_pairs_f(const Geom &g, const TapCoef<ND, A> &tc, const A *fl,
+                                             const A *fh, A scale, int (&idx)[1 << (ND - 1)],
+                                             A (&wx)[1 << (ND - 1)], A (&wy)[1 << (ND - 1)]) {
+  // fl[a] / fh[a]: factor of the low / high side on axis a (weights, or -1/+1 derivative factors)
   constexpr int L = ND - 1;
   const int lc = tc.last_lc, hc = tc.last_lc + tc.delta[L];
   const int cl = min(lc, g.in_sz[L] - 2);
-  const A xw = (lc == cl ? tc.wl[L] : (A)0) + (hc == cl ? tc.wh[L] : (A)0);
-  const A yw = (lc == cl + 1 ? tc.wl[L] : (A)0) + (hc == cl + 1 ? tc.wh[L] : (A)0);
+  const A xw = (lc == cl ? fl[L] : (A)0) + (hc == cl ? fh[L] : (A)0);
+  const A yw = (lc == cl + 1 ? fl[L] : (A)0) + (hc == cl + 1 ? fh[L] : (A)0);
 #pragma unroll
   for (int pi = 0; pi < (1 << L); ++pi) {
     int id = tc.base - lc + cl;
@@ -197,12 +198,31 @@ __device__ __forceinline__ void make_pairs(const Geom &g, const TapCoef<ND, A> &
     for (int a = 0; a < L; ++a) {
       const bool hi = (pi >> (L - 1 - a)) & 1;
       id += hi ? tc.delta[a] : 0;
-      w *= hi ? tc.wh[a] : tc.wl[a];
+      w *= hi ? fh[a] : fl[a];
     }
     idx[pi] = id;
     wx[pi] = w * xw;
     wy[pi] = w * yw;
   }
+}
+template <int ND, typename A>
+__device__ __forceinline__ void make_pairs(const Geom &g, const TapCoef<ND, A> &tc, A scale,
+                                           int (&idx)[1 << (ND - 1)], A (&wx)[1 << (ND - 1)],
+                                           A (&wy)[1 << (ND - 1)]) {
+  make_pairs_f<ND, A>(g, tc, tc.wl, tc.wh, scale, idx, wx, wy);
+}
+// same pairs, weights of d(val)/d(p_axis)
+template <int ND, typename A>
+__device__ __forceinline__ void make_pairs_d(const Geom &g, const TapCoef<ND, A> &tc, int axis,
+                                             A (&wx)[1 << (ND - 1)], A (&wy)[1 << (ND - 1)]) {
+  A fl[ND], fh[ND];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    fl[a] = a == axis ? tc.sl[a] : tc.wl[a];
+    fh[a] = a == axis ? tc.sh[a] : tc.wh[a];
+  }
+  int idx[1 << (ND - 1)];
+  make_pairs_f<ND, A>(g, tc, fl, fh, (A)1, idx, wx, wy);
 }
 
 // ---- host-side helpers ------------------------------------------------------------------------

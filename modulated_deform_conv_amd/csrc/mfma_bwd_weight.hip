@@ -26,21 +26,23 @@ namespace {
 constexpr int kPitch = 33;
 
 // ---------------------------------------------------------------------------------------------
-// tap table: per (dg, tap, n) the 2^ND corner byte offsets (image base folded in) and weights
-// (validity, backward load gating and the mask folded in).  Entry = [2][NC] words.
+// tap table: per (dg, tap, n) the byte offsets of the 2^(ND-1) corner PAIRS (image base folded
+// in; the two neighbours along the contiguous axis are fetched by one 8-byte load) and the 2^ND
+// weights (validity, backward load gating and the mask folded in).
+// Entry = kTabWords(ND) words: [NP offsets | pad][NC weights]  (8 words in 2-D, 16 in 3-D).
 // ---------------------------------------------------------------------------------------------
 template <int ND, bool MOD>
 __global__ __launch_bounds__(256) void tap_table_kernel(Geom g, int Np, const float *__restrict__ offset,
                                                         const float *__restrict__ mask,
                                                         int *__restrict__ table) {
-  constexpr int NC = 1 << ND;
+  constexpr int NC = 1 << ND, NP = NC / 2, TW = 2 * NC;   // TW words per entry
   const int64_t total = (int64_t)g.DG * g.K * Np;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int n = (int)(i % Np);
     const int tap = (int)((i / Np) % g.K);
     const int dg = (int)(i / Np / g.K);
-    int vo[NC];
-    float w[NC];
+    int vo[NP];
+    float wx[NP], wy[NP];
     if (n < g.N) {
       const int b = n / g.S_o, pix = n - b * g.S_o;
       int oc[ND], tcd[ND];
@@ -53,20 +55,20 @@ __global__ __launch_bounds__(256) void tap_table_kernel(Geom g, int Np, const fl
       TapCoef<ND, float> tc;
       make_tap<ND, float>(g, oc, tcd, delta, true, tc);
       const float m = MOD ? mask[((int64_t)(b * g.DG + dg) * g.K + tap) * g.S_o + pix] : 1.f;
+      make_pairs<ND, float>(g, tc, m, vo, wx, wy);
 #pragma unroll
-      for (int ci = 0; ci < NC; ++ci) {
-        vo[ci] = (b * g.C * g.S_i + corner_index<ND, float>(tc, ci)) * 4;
-        w[ci] = corner_weight<ND, float>(tc, ci) * m;
-      }
+      for (int pi = 0; pi < NP; ++pi) vo[pi] = (b * g.C * g.S_i + vo[pi]) * 4;
     } else {
 #pragma unroll
-      for (int ci = 0; ci < NC; ++ci) { vo[ci] = 0; w[ci] = 0.f; }
+      for (int pi = 0; pi < NP; ++pi) { vo[pi] = 0; wx[pi] = 0.f; wy[pi] = 0.f; }
     }
-    int *e = table + i * (2 * NC);
+    int *e = table + i * TW;
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {
-      e[ci] = vo[ci];
-      e[NC + ci] = __float_as_int(w[ci]);
+    for (int pi = 0; pi < NP; ++pi) {
+      e[pi] = vo[pi];
+      e[NP + pi] = 0;
+      e[NC + 2 * pi] = __float_as_int(wx[pi]);
+      e[NC + 2 * pi + 1] = __float_as_int(wy[pi]);
     }
   }
 }
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
                                                               const float *__restrict__ ga,
                                                               const int *__restrict__ table,
                                                               float *__restrict__ part) {
-  constexpr int NC = 1 << ND;
+  constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int BK = kBK, BN = 32, MB = 2;
   __shared__ __attribute__((aligned(16))) float Bs[2 * BK * kPitch];
 
@@ -155,33 +157,44 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  struct Tab { int vo[NC]; float w[NC]; };
+  struct Tab { int vo[NP]; float w[NC]; };
   auto load_tab = [&](Tab &tb, int t) {
     const int soff = t * 16 * entry_bytes;
+    if constexpr (ND == 2) {
+      const float4 a = buf_load4(r_tab, t_voff, soff);            // [vo0 vo1 - -]
+      tb.vo[0] = __float_as_int(a.x); tb.vo[1] = __float_as_int(a.y);
+      const float4 b = buf_load4(r_tab, t_voff + 16, soff);
+      tb.w[0] = b.x; tb.w[1] = b.y; tb.w[2] = b.z; tb.w[3] = b.w;
+    } else {
+      const float4 a = buf_load4(r_tab, t_voff, soff);            // [vo0..vo3]
+      tb.vo[0] = __float_as_int(a.x); tb.vo[1] = __float_as_int(a.y);
+      tb.vo[2] = __float_as_int(a.z); tb.vo[3] = __float_as_int(a.w);
 #pragma unroll
-    for (int h = 0; h < NC / 4; ++h) {
-      const float4 a = buf_load4(r_tab, t_voff + h * 16, soff);
-      tb.vo[4 * h + 0] = __float_as_int(a.x); tb.vo[4 * h + 1] = __float_as_int(a.y);
-      tb.vo[4 * h + 2] = __float_as_int(a.z); tb.vo[4 * h + 3] = __float_as_int(a.w);
-      const float4 b = buf_load4(r_tab, t_voff + NC * 4 + h * 16, soff);
-      tb.w[4 * h + 0] = b.x; tb.w[4 * h + 1] = b.y; tb.w[4 * h + 2] = b.z; tb.w[4 * h + 3] = b.w;
+      for (int h = 0; h < NC / 4; ++h) {
+        const float4 b = buf_load4(r_tab, t_voff + NC * 4 + h * 16, soff);
+        tb.w[4 * h + 0] = b.x; tb.w[4 * h + 1] = b.y; tb.w[4 * h + 2] = b.z; tb.w[4 * h + 3] = b.w;
+      }
     }
   };
-  float rg[2][NC];
+  float2 rg[2][NP];
   auto gather = [&](const Tab &tb) {
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {
-      const int vo = tb.vo[ci] + chan_voff;
-      rg[0][ci] = buf_load(r_in, vo, 0);
-      rg[1][ci] = buf_load(r_in, vo, chan_soff);
+    for (int pi = 0; pi < NP; ++pi) {
+      const int vo = tb.vo[pi] + chan_voff;
+      rg[0][pi] = buf_load2(r_in, vo, 0);
+      rg[1][pi] = buf_load2(r_in, vo, chan_soff);
     }
   };
   auto commit = [&](const Tab &tb, int t, float *Bb) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      float val = tb.w[0] * rg[i][0];
+      float val = tb.w[0] * rg[i][0].x;
+      val = fmaf(tb.w[1], rg[i][0].y, val);
 #pragma unroll
-      for (int ci = 1; ci < NC; ++ci) val = fmaf(tb.w[ci], rg[i][ci], val);
+      for (int pi = 1; pi < NP; ++pi) {
+        val = fmaf(tb.w[2 * pi], rg[i][pi].x, val);
+        val = fmaf(tb.w[2 * pi + 1], rg[i][pi].y, val);
+      }
       if (PADN) val = (t * 16 + kk < g.N) ? val : 0.f;
       Bb[kk * kPitch + sub + 16 * i] = val;
     }
