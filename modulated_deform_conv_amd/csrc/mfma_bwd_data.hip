@@ -71,12 +71,12 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
     int ntiles) {
-  constexpr int NC = 1 << ND;
+  constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int BK = kBK, MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
   constexpr int BNP = 32 * WAVES_P;        // pixels per workgroup
   constexpr int BPT = BK * BNP / 256;      // grad_out elements per thread per chunk
-  constexpr int RB = 32 / NC;              // accumulator rows gathered per batch (32 loads)
+  constexpr int RB = 8;                    // accumulator rows gathered per batch
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * BNP];
 
   const int tile = xcd_remap(blockIdx.x, ntiles);
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
 
   for (int tap = 0; tap < g.K; ++tap) {
     // ---- sampling state of (tap, this lane's pixel) ----
-    int voff[NC];
+    // corner PAIRS (make_pairs): byte offsets, value weights and d/dp weights of both elements
+    int voff[NP];
     float w[NC], dw[ND][NC];
     float m = 1.f;
     bool inside;
@@ -129,16 +130,27 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
       make_tap<ND, float>(g, oc, tcd, delta, true, tc);
       if (MOD) m = mask[((int64_t)b_l * g.K + tap) * g.S_o + pix_l];
       inside = tc.inside;
+      int pidx[NP];
+      float px[NP], py[NP];
+      make_pairs<ND, float>(g, tc, 1.f, pidx, px, py);
 #pragma unroll
-      for (int ci = 0; ci < NC; ++ci) {
-        voff[ci] = (b_l * g.C * g.S_i + corner_index<ND, float>(tc, ci) + 4 * kh * g.S_i) * 4;
-        w[ci] = corner_weight<ND, float>(tc, ci);
+      for (int pi = 0; pi < NP; ++pi) {
+        voff[pi] = (b_l * g.C * g.S_i + pidx[pi] + 4 * kh * g.S_i) * 4;
+        w[2 * pi] = px[pi];
+        w[2 * pi + 1] = py[pi];
+      }
 #pragma unroll
-        for (int a = 0; a < ND; ++a) dw[a][ci] = corner_dweight<ND, float>(tc, ci, a);
+      for (int a = 0; a < ND; ++a) {
+        make_pairs_d<ND, float>(g, tc, a, px, py);
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+          dw[a][2 * pi] = px[pi];
+          dw[a][2 * pi + 1] = py[pi];
+        }
       }
     }
     const int gc_voff = ((((b_l * g.K + tap) * g.S_o + pix_l) * g.C) + 4 * kh) * 4;
-    // S[ci] = sum over this lane's channels of grad_col * corner value.  The corner weights and
+    // S[e] = sum over this lane's channels of grad_col * (element e of the corner pairs).  The corner weights and
     // their derivatives do not depend on the channel, so the epilogue costs 2^ND FMAs per channel
     // and grad_mask / grad_offset are recovered from S once per tap:
     //   grad_mask += sum_ci w[ci] S[ci],   grad_offset_a += m * sum_ci dw[a][ci] S[ci].
@@ -211,8 +223,8 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
       // which cost 284 VGPRs and occupancy 1).
       if (cbase < g.C) {
         constexpr int NBATCH = MB * 16 / RB;
-        float v[2][RB][NC];
-        auto gather_batch = [&](float (&vb)[RB][NC], int k) {
+        float2 v[2][RB][NP];
+        auto gather_batch = [&](float2 (&vb)[RB][NP], int k) {
           const int mb = (k * RB) / 16, r0 = (k * RB) % 16;
 #pragma unroll
           for (int rr = 0; rr < RB; ++rr) {
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
             const int cu = cbase + mb * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh is in the voffset
             const int cs = min(cu, g.C - 5) * g.S_i * 4;   // cu % 8 < 4, so C-5 is the last valid one
 #pragma unroll
-            for (int ci = 0; ci < NC; ++ci) vb[rr][ci] = buf_load(r_in, voff[ci], cs);
+            for (int pi = 0; pi < NP; ++pi) vb[rr][pi] = buf_load2(r_in, voff[pi], cs);
           }
         };
 #ifdef ABL_SINGLEBUF
@@ -255,7 +267,10 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
           for (int rr = 0; rr < RB; ++rr) {
             const float gc = acc[mb][r0 + rr];
 #pragma unroll
-            for (int ci = 0; ci < NC; ++ci) S[ci] = fmaf(gc, v[VB(k)][rr][ci], S[ci]);
+            for (int pi = 0; pi < NP; ++pi) {
+              S[2 * pi] = fmaf(gc, v[VB(k)][rr][pi].x, S[2 * pi]);
+              S[2 * pi + 1] = fmaf(gc, v[VB(k)][rr][pi].y, S[2 * pi + 1]);
+            }
           }
 #pragma unroll
           for (int ci = 0; ci < NC; ++ci) asm volatile("" : "+v"(S[ci]));   // pin the updates here
