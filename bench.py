@@ -89,7 +89,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # under torchrun (RANK set) the collective path is exercised even with one process
+    distributed = world > 1 or (os.environ.get("MDCONV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -97,6 +98,8 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"   # the image's default prints a banner on stdout
         dist.init_process_group("nccl", device_id=device)
 
     from modulated_deform_conv_amd import MDCONV_CUDA as M, _capi

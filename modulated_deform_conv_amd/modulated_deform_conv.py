@@ -13,6 +13,7 @@ import math
 import torch
 import torch.nn as nn
 from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair, _triple
 
@@ -124,8 +125,10 @@ def _make_function(nd, modulated, name):
         return _output_shape(input, weight, ctx.stride, ctx.padding, ctx.dilation)
 
     return type(name, (Function,), {
-        "forward": staticmethod(forward),
-        "backward": staticmethod(once_differentiable(_backward)),
+        # AMP: under torch.autocast the op runs in fp32 -- coordinates and
+        # accumulation need it -- and autocast is disabled inside backward.
+        "forward": staticmethod(custom_fwd(forward, device_type="cuda", cast_inputs=torch.float32)),
+        "backward": staticmethod(custom_bwd(once_differentiable(_backward), device_type="cuda")),
         "_infer_shape": staticmethod(_infer_shape),
         "__doc__": "%s-D %sdeformable convolution (reference modulated_deform_conv.py)." % (
             nd, "modulated " if modulated else ""),
@@ -227,14 +230,15 @@ class _PackMixin:
             self.conv_mask = conv(self.in_channels, self.deformable_groups * K,
                                   kernel_size=self.kernel_size, stride=self.stride,
                                   padding=self.padding, bias=True)
-        stdv = 1. / math.sqrt(self.in_channels * K)
+        self.init_offset()
+
+    def init_offset(self):
+        """(Re-)initialise the side convolutions (reference init_offset / init_offset_mask)."""
+        stdv = 1. / math.sqrt(self.in_channels * math.prod(self.kernel_size))
         for m in (self.conv_offset, getattr(self, "conv_mask", None)):
             if m is not None:
                 m.weight.data.uniform_(-stdv, stdv)
                 m.bias.data.zero_()
-
-    def init_offset(self):
-        self._make_side_convs() if not hasattr(self, "conv_offset") else None
 
     init_offset_mask = init_offset
 

@@ -87,3 +87,20 @@ def test_pack_module_runs():
     y.square().mean().backward()
     assert y.shape == (2, 8, 10, 10) and torch.isfinite(x.grad).all()
     assert m.conv_offset.weight.grad is not None and m.conv_mask.weight.grad is not None
+
+
+def test_autocast_runs_in_fp32():
+    """AMP integration: under autocast the op computes in fp32 and returns fp32."""
+    from modulated_deform_conv_amd import modulated_deform_conv as mdc
+    torch.manual_seed(0)
+    m = mdc.ModulatedDeformConv2d(16, 16, 3, padding=1, bias=True).cuda()
+    x = torch.randn(2, 16, 9, 9, device="cuda", requires_grad=True)
+    off = torch.randn(2, 18, 9, 9, device="cuda")
+    mask = torch.rand(2, 9, 9, 9, device="cuda")
+    ref = m(x, off, mask)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = m(x.half(), off.half(), mask)        # mixed input dtypes are fine under autocast
+    assert y.dtype == torch.float32
+    assert_close("autocast", y, m(x.half().float(), off.half().float(), mask), 1e-5)
+    y.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and ref.shape == y.shape
