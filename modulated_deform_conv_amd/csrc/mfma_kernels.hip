@@ -2,6 +2,8 @@
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
 
+#include <stdlib.h>
+
 #include <vector>
 
 namespace mdconv {
@@ -92,57 +94,141 @@ BwdDims bwd_dims(const Geom &g) {
   bd.off_table = off; off += align_up((size_t)g.DG * g.K * bd.Np * 2 * (1 << g.nd) * sizeof(int));
   bd.off_part = off; off += align_up((size_t)bd.splits * g.K * bd.OgpB * bd.Cp * sizeof(float));
   bd.off_gcol = off; off += align_up((size_t)g.B * g.C * g.K * g.S_o * sizeof(float));
-  bd.off_cnt = off;  off += align_up((size_t)g.B * g.K * g.S_i * sizeof(int));
-  bd.off_rowptr = off; off += align_up((size_t)g.B * g.K * (g.S_i + 1) * sizeof(int));
+  bd.off_cnt = off;  off += align_up((size_t)g.B * g.S_i * sizeof(int));
+  bd.off_rowptr = off; off += align_up((size_t)g.B * (g.S_i + 1) * sizeof(int));
   bd.off_entries = off; off += align_up((size_t)g.B * g.K * g.S_o * nc * 8);
   bd.off_end = off;
   return bd;
 }
 
-bool mfma_supported(const Geom &g, int dtype, bool backward) {
-  if (dtype != MDCONV_F32) return false;
-  if (g.Cg < 16 || g.Og < 16) return false;  // MFMA tiles would be mostly padding
-  if (g.in_sz[g.nd - 1] < 2) return false;   // paired-corner gathers need 2 columns
-  if (!(g.DG == 1 || (g.Cdg % (2 * kBK) == 0 && g.Cg % (2 * kBK) == 0))) return false;
-  // raw buffer addressing: every tensor must stay below 2 GiB
-  if ((size_t)g.B * g.C * g.S_i * sizeof(float) >= ((size_t)1 << 31)) return false;
-  if (backward) {
-    if (g.G != 1 || g.DG != 1 || g.C % 8) return false;
-    if ((size_t)g.B * g.O * g.S_o * sizeof(float) >= ((size_t)1 << 31)) return false;
-    if ((size_t)g.B * g.C * g.K * g.S_o * sizeof(float) >= ((size_t)1 << 31)) return false;  // grad_col
+// ---------------------------------------------------------------------------------------------
+// Execution plan: batch chunking + fp16 I/O.
+//  * The kernels address tensors with 32-bit byte offsets (raw buffer loads), so a call is cut
+//    into chunks of Bc images such that every per-chunk tensor (and the grad_col workspace)
+//    stays below 2 GiB.  grad_weight / grad_bias accumulate across chunks by construction.
+//    (This is the only thing left of the reference's `in_step` chunk loop.)
+//  * fp16 tensors are computed in fp32: each chunk is widened into fp32 copies in the workspace,
+//    run through the fp32 kernels (coordinates and accumulation in fp32) and
+//    narrowed back; grad_weight / grad_bias are accumulated in fp32 over all chunks.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// 2 GiB minus slack; MDCONV_CHUNK_LIMIT_BYTES lowers it so tests can force multi-chunk execution
+size_t chunk_limit() {
+  static size_t lim = 0;
+  if (!lim) {
+    lim = ((size_t)1 << 31) - (1 << 16);
+    const char *e = getenv("MDCONV_CHUNK_LIMIT_BYTES");
+    if (e && atoll(e) > 0 && (size_t)atoll(e) < lim) lim = (size_t)atoll(e);
   }
+  return lim;
+}
+
+struct Plan {
+  int Bc;
+  bool half_io;
+  Geom gc;            // geometry of a full chunk
+  size_t core_bytes;  // workspace of the fp32 kernels for one chunk
+  size_t off_w, off_b, off_x, off_off, off_m, off_go, off_out, off_gi, off_goff, off_gm, off_gw, off_gb;
+  size_t total;
+};
+
+Geom chunk_geom(const Geom &g, int bc) {
+  Geom c = g;
+  c.B = bc;
+  c.N = bc * g.S_o;
+  return c;
+}
+
+size_t core_bytes_for(const Geom &gc, bool backward) {
+  if (backward) return bwd_dims(gc).off_end;
+  const PackDims pd = pack_dims(gc);
+  return align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float));
+}
+
+bool make_plan(const Geom &g, int dtype, bool backward, Plan *p) {
+  const size_t per_in = (size_t)g.C * g.S_i * 4, per_out = (size_t)g.O * g.S_o * 4;
+  const size_t per_col = (size_t)g.C * g.K * g.S_o * 4;
+  size_t per = per_in > per_out ? per_in : per_out;
+  if (backward && per_col > per) per = per_col;
+  const size_t kLim = chunk_limit();
+  if (per >= kLim) return false;
+  int bc = (int)(kLim / per);
+  if (bc > g.B) bc = g.B;
+  p->Bc = bc;
+  p->half_io = dtype == MDCONV_F16;
+  p->gc = chunk_geom(g, bc);
+  p->core_bytes = core_bytes_for(p->gc, backward);
+  size_t off = p->core_bytes;
+  auto take = [&](size_t &slot, size_t elems) { slot = off; off += align_up(elems * sizeof(float)); };
+  p->off_w = p->off_b = p->off_x = p->off_off = p->off_m = p->off_go = p->off_out = 0;
+  p->off_gi = p->off_goff = p->off_gm = p->off_gw = p->off_gb = 0;
+  if (p->half_io) {
+    const int nc_off = g.DG * g.nd * g.K, nc_m = g.DG * g.K;
+    take(p->off_w, (size_t)g.O * g.Cg * g.K);
+    take(p->off_b, (size_t)g.O);
+    take(p->off_x, (size_t)bc * g.C * g.S_i);
+    take(p->off_off, (size_t)bc * nc_off * g.S_o);
+    take(p->off_m, (size_t)bc * nc_m * g.S_o);
+    if (!backward) {
+      take(p->off_out, (size_t)bc * g.O * g.S_o);
+    } else {
+      take(p->off_go, (size_t)bc * g.O * g.S_o);
+      take(p->off_gi, (size_t)bc * g.C * g.S_i);
+      take(p->off_goff, (size_t)bc * nc_off * g.S_o);
+      take(p->off_gm, (size_t)bc * nc_m * g.S_o);
+      take(p->off_gw, (size_t)g.O * g.Cg * g.K);
+      take(p->off_gb, (size_t)g.O);
+    }
+  }
+  p->total = off;
   return true;
 }
 
-size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
-  (void)dtype;
-  if (backward) return bwd_dims(g).off_end;
-  const PackDims pd = pack_dims(g);
-  return align_up((size_t)g.G * g.K * pd.Cgp * pd.Ogp * sizeof(float));
+__global__ __launch_bounds__(256) void widen_kernel(const __half *__restrict__ src, float *__restrict__ dst,
+                                                    int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dst[i] = __half2float(src[i]);
+}
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void narrow_kernel(const float *__restrict__ src, __half *__restrict__ dst,
+                                                     int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dst[i] = __float2half(ACCUM ? __half2float(dst[i]) + src[i] : src[i]);
+}
+int nblocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+int widen(const void *src, float *dst, int64_t n, hipStream_t s) {
+  if (n == 0) return MDCONV_OK;
+  hipLaunchKernelGGL(widen_kernel, dim3(nblocks(n)), dim3(256), 0, s, (const __half *)src, dst, n);
+  return check_launch("widen");
+}
+int narrow(const float *src, void *dst, int64_t n, bool accum, hipStream_t s) {
+  if (n == 0) return MDCONV_OK;
+  if (accum)
+    hipLaunchKernelGGL(narrow_kernel<true>, dim3(nblocks(n)), dim3(256), 0, s, src, (__half *)dst, n);
+  else
+    hipLaunchKernelGGL(narrow_kernel<false>, dim3(nblocks(n)), dim3(256), 0, s, src, (__half *)dst, n);
+  return check_launch("narrow");
+}
+int zero(void *p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return MDCONV_OK;
+  const hipError_t e = hipMemsetAsync(p, 0, bytes, s);
+  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
+  return MDCONV_OK;
 }
 
-int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
-  (void)dtype;
-  const PackDims pd = pack_dims(g);
-  float *wp = (float *)ws;
-  int rc = pack_weights_f32(g, pd, (const float *)t.weight, wp, nullptr, stream);
-  if (rc) return rc;
-  profile_mark(0, true, stream);
-  rc = mfma_forward_f32(g, pd, t, wp, stream);
-  profile_mark(0, false, stream);
-  return rc;
-}
-
-int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+// fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`)
+int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t stream) {
   const BwdDims bd = bwd_dims(g);
-  char *base = (char *)ws;
+  float *wq = (float *)(base + bd.off_wq);
   float *ga = (float *)(base + bd.off_ga);
   int *table = (int *)(base + bd.off_table);
   float *part = (float *)(base + bd.off_part);
-  float *wq = (float *)(base + bd.off_wq);
   float *gcol = (float *)(base + bd.off_gcol);
   int rc;
-  (void)dtype;
   // grad_offset / grad_mask (+ grad_col), then grad_input through the inverted scatter map
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
   profile_mark(1, true, stream);
@@ -158,6 +244,129 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
   return mfma_bwd_weight_f32(g, bd, t, ga, table, part, stream);
 }
 
+}  // namespace
+
+bool mfma_supported(const Geom &g, int dtype, bool backward) {
+  if (dtype != MDCONV_F32 && dtype != MDCONV_F16) return false;
+  if (g.Cg < 16 || g.Og < 16) return false;  // MFMA tiles would be mostly padding
+  if (g.in_sz[g.nd - 1] < 2) return false;   // paired-corner gathers need 2 columns
+  if (!(g.DG == 1 || (g.Cdg % (2 * kBK) == 0 && g.Cg % (2 * kBK) == 0))) return false;
+  if (backward && (g.G != 1 || g.DG != 1 || g.C % 8)) return false;
+  Plan p;
+  return make_plan(g, dtype, backward, &p);   // one image must fit 32-bit buffer offsets
+}
+
+size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
+  Plan p;
+  if (!make_plan(g, dtype, backward, &p)) return 0;
+  return p.total;
+}
+
+int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  Plan p;
+  if (!make_plan(g, dtype, false, &p)) { set_error("mfma_forward: no plan"); return MDCONV_EUNSUPPORTED; }
+  char *base = (char *)ws;
+  const size_t es = p.half_io ? 2 : 4;
+  const int nc_off = g.DG * g.nd * g.K, nc_m = g.DG * g.K;
+  int rc;
+  const float *w32 = (const float *)t.weight, *b32 = (const float *)t.bias;
+  if (p.half_io) {
+    if ((rc = widen(t.weight, (float *)(base + p.off_w), (int64_t)g.O * g.Cg * g.K, stream))) return rc;
+    if (g.with_bias && (rc = widen(t.bias, (float *)(base + p.off_b), g.O, stream))) return rc;
+    w32 = (const float *)(base + p.off_w);
+    b32 = (const float *)(base + p.off_b);
+  }
+  const PackDims pd = pack_dims(p.gc);
+  float *wp = (float *)base;
+  if ((rc = pack_weights_f32(p.gc, pd, w32, wp, nullptr, stream))) return rc;
+  for (int b0 = 0; b0 < g.B; b0 += p.Bc) {
+    const int bc = g.B - b0 < p.Bc ? g.B - b0 : p.Bc;
+    const Geom gc = chunk_geom(g, bc);
+    Tensors tc = {};
+    const char *x = (const char *)t.input + (size_t)b0 * g.C * g.S_i * es;
+    const char *of = (const char *)t.offset + (size_t)b0 * nc_off * g.S_o * es;
+    const char *mk = t.mask ? (const char *)t.mask + (size_t)b0 * nc_m * g.S_o * es : nullptr;
+    char *out = (char *)t.output + (size_t)b0 * g.O * g.S_o * es;
+    tc.weight = w32;
+    tc.bias = b32;
+    if (p.half_io) {
+      if ((rc = widen(x, (float *)(base + p.off_x), (int64_t)bc * g.C * g.S_i, stream))) return rc;
+      if ((rc = widen(of, (float *)(base + p.off_off), (int64_t)bc * nc_off * g.S_o, stream))) return rc;
+      if (mk && (rc = widen(mk, (float *)(base + p.off_m), (int64_t)bc * nc_m * g.S_o, stream))) return rc;
+      tc.input = base + p.off_x;
+      tc.offset = base + p.off_off;
+      tc.mask = mk ? base + p.off_m : nullptr;
+      tc.output = base + p.off_out;
+    } else {
+      tc.input = x; tc.offset = of; tc.mask = mk; tc.output = out;
+    }
+    profile_mark(0, true, stream);
+    rc = mfma_forward_f32(gc, pd, tc, wp, stream);
+    profile_mark(0, false, stream);
+    if (rc) return rc;
+    if (p.half_io && (rc = narrow((const float *)tc.output, out, (int64_t)bc * g.O * g.S_o, false, stream)))
+      return rc;
+  }
+  return MDCONV_OK;
+}
+
+int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  Plan p;
+  if (!make_plan(g, dtype, true, &p)) { set_error("mfma_backward: no plan"); return MDCONV_EUNSUPPORTED; }
+  char *base = (char *)ws;
+  const size_t es = p.half_io ? 2 : 4;
+  const int nc_off = g.DG * g.nd * g.K, nc_m = g.DG * g.K;
+  const int64_t n_w = (int64_t)g.O * g.Cg * g.K;
+  int rc;
+  if (p.half_io) {
+    if ((rc = widen(t.weight, (float *)(base + p.off_w), n_w, stream))) return rc;
+    if ((rc = zero(base + p.off_gw, n_w * 4, stream)) || (rc = zero(base + p.off_gb, (size_t)g.O * 4, stream)))
+      return rc;
+  }
+  for (int b0 = 0; b0 < g.B; b0 += p.Bc) {
+    const int bc = g.B - b0 < p.Bc ? g.B - b0 : p.Bc;
+    const Geom gc = chunk_geom(g, bc);
+    const size_t o_x = (size_t)b0 * g.C * g.S_i, o_off = (size_t)b0 * nc_off * g.S_o;
+    const size_t o_m = (size_t)b0 * nc_m * g.S_o, o_go = (size_t)b0 * g.O * g.S_o;
+    Tensors tc = t;
+    if (p.half_io) {
+      const int64_t n_x = (int64_t)bc * g.C * g.S_i, n_off = (int64_t)bc * nc_off * g.S_o;
+      const int64_t n_m = (int64_t)bc * nc_m * g.S_o, n_go = (int64_t)bc * g.O * g.S_o;
+      if ((rc = widen((const char *)t.input + o_x * es, (float *)(base + p.off_x), n_x, stream))) return rc;
+      if ((rc = widen((const char *)t.offset + o_off * es, (float *)(base + p.off_off), n_off, stream))) return rc;
+      if (t.mask && (rc = widen((const char *)t.mask + o_m * es, (float *)(base + p.off_m), n_m, stream))) return rc;
+      if ((rc = widen((const char *)t.grad_output + o_go * es, (float *)(base + p.off_go), n_go, stream))) return rc;
+      if ((rc = zero(base + p.off_gi, n_x * 4, stream)) || (rc = zero(base + p.off_goff, n_off * 4, stream)) ||
+          (rc = zero(base + p.off_gm, n_m * 4, stream)))
+        return rc;
+      tc.input = base + p.off_x; tc.offset = base + p.off_off; tc.mask = t.mask ? base + p.off_m : nullptr;
+      tc.weight = base + p.off_w; tc.grad_output = base + p.off_go;
+      tc.grad_input = base + p.off_gi; tc.grad_offset = base + p.off_goff;
+      tc.grad_mask = t.grad_mask ? base + p.off_gm : nullptr;
+      tc.grad_weight = base + p.off_gw; tc.grad_bias = base + p.off_gb;
+      if ((rc = backward_chunk_f32(gc, tc, base, stream))) return rc;
+      if ((rc = narrow((const float *)tc.grad_input, (char *)t.grad_input + o_x * es, n_x, true, stream))) return rc;
+      if ((rc = narrow((const float *)tc.grad_offset, (char *)t.grad_offset + o_off * es, n_off, true, stream))) return rc;
+      if (t.grad_mask &&
+          (rc = narrow((const float *)tc.grad_mask, (char *)t.grad_mask + o_m * es, n_m, true, stream)))
+        return rc;
+    } else {
+      tc.input = (const char *)t.input + o_x * es;
+      tc.offset = (const char *)t.offset + o_off * es;
+      tc.mask = t.mask ? (const char *)t.mask + o_m * es : nullptr;
+      tc.grad_output = (const char *)t.grad_output + o_go * es;
+      tc.grad_input = (char *)t.grad_input + o_x * es;
+      tc.grad_offset = (char *)t.grad_offset + o_off * es;
+      tc.grad_mask = t.grad_mask ? (char *)t.grad_mask + o_m * es : nullptr;
+      if ((rc = backward_chunk_f32(gc, tc, base, stream))) return rc;
+    }
+  }
+  if (p.half_io) {
+    if ((rc = narrow((const float *)(base + p.off_gw), t.grad_weight, n_w, true, stream))) return rc;
+    if (g.with_bias && (rc = narrow((const float *)(base + p.off_gb), t.grad_bias, g.O, true, stream))) return rc;
+  }
+  return MDCONV_OK;
+}
 
 }  // namespace mdconv
 

@@ -89,3 +89,34 @@ def test_error_behaviour_on_device():
         M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo[:10], 0, False)
     out = M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo)
     assert out.shape == (2, 4, 6, 6)
+
+
+def test_batch_chunking_matches_unchunked():
+    """Calls whose tensors exceed the 32-bit buffer range are cut into batch chunks inside the C ABI
+    (the successor of the reference's in_step loop).  Force tiny chunks in a subprocess and compare
+    with the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import torch, sys
+sys.path.insert(0, %r)
+from tests.cases import CASE_BY_NAME, make_inputs
+from tests.util import run_product, run_oracle, assert_close
+from modulated_deform_conv_amd import _capi
+for name, dt, tol in (("cfg2s_mdcn2d_c64_28x28_b4", torch.float32, 1e-4), ("cfg2s_mdcn2d_c64_28x28_b4", torch.float16, 2e-2),
+                      ("cfg4s_dcn3d_c16_12cubed_b2", torch.float32, 1e-4)):
+    case = CASE_BY_NAME[name]
+    t = make_inputs(case, dtype=dt, device="cuda")
+    out, g, paths = run_product(case, t, "mfma")
+    assert paths == ["mfma", "mfma"], paths
+    wo, w = run_oracle(case, t, torch.float32)
+    assert_close("output", out, wo, tol)
+    for k in g:
+        if w[k] is not None:
+            assert_close(k, g[k], w[k], tol)
+print("CHUNK_OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDCONV_CHUNK_LIMIT_BYTES=str(4 * 1024 * 1024))   # 2 or 1 images per chunk at these sizes
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "CHUNK_OK" in r.stdout, r.stdout + r.stderr
