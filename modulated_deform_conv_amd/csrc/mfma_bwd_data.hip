@@ -65,6 +65,14 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
 // ---------------------------------------------------------------------------------------------
 // 1. GEMM-1 + coordinate gradients + grad_col stream
 // ---------------------------------------------------------------------------------------------
+// The grad_out tile of the workgroup ([C_out] x BNP pixels, 32 KB at cfg2) does not depend on the
+// tap, so it is loaded into LDS ONCE, o-innermost, and the K loops of all taps read their B
+// fragments from it with two ds_read_b128 per 16 MFMAs: no global B loads, no LDS writes and no
+// barriers inside the tap loop, so the four waves drift apart and one wave's gather epilogue
+// overlaps the others' MFMAs.  The per-tap channel reduction goes through a small LDS buffer
+// that is flushed every kTapGroup taps (the only barriers left).
+constexpr int kTapGroup = 9;
+
 template <int ND, bool MOD, int WAVES_C>
 __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
@@ -72,12 +80,15 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
     int ntiles) {
   constexpr int NC = 1 << ND, NP = NC / 2;
-  constexpr int BK = kBK, MB = 2;
+  constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
   constexpr int BNP = 32 * WAVES_P;        // pixels per workgroup
-  constexpr int BPT = BK * BNP / 256;      // grad_out elements per thread per chunk
   constexpr int RB = 8;                    // accumulator rows gathered per batch
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * BNP];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int T_o = bd.ochunks;              // even
+  const int gpitch = T_o * 16 + 4;         // floats per pixel row of the grad_out tile
+  float *Gs = smem;                        // [BNP][gpitch]
+  float *red = smem + BNP * gpitch;        // [kTapGroup][WAVES_C][ND + 1][BNP]
 
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int n0 = tile * BNP;
@@ -87,6 +98,23 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WAVES_P, wp = wave % WAVES_P;
 
+  // ---- grad_out tile -> LDS (once) ----
+  {
+    const int j = tid % BNP, osub = tid / BNP;
+    constexpr int OSTEP = 256 / BNP;
+    const int n_t = min(n0 + j, g.N - 1);
+    const int b_t = n_t / g.S_o, pix_t = n_t - b_t * g.S_o;
+    const bool t_live = n0 + j < g.N;
+    const float *src = gout + ((int64_t)b_t * g.O) * g.S_o + pix_t;
+    float *dst = Gs + j * gpitch;
+    const int Opad = T_o * 16;
+#pragma unroll 8
+    for (int o = osub; o < Opad; o += OSTEP) {
+      const float v = src[(int64_t)min(o, g.O - 1) * g.S_o];
+      dst[o] = (t_live && o < g.O) ? v : 0.f;
+    }
+  }
+
   // the pixel this lane owns in the accumulator layout
   const int n_raw = n0 + wp * 32 + (lane & 31);
   const bool live = n_raw < g.N;
@@ -95,22 +123,35 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
   int oc[ND];
   out_coords<ND>(g, pix_l, oc);
 
-  // grad_out slab: thread -> (pixel j, rows osub*BPT ..)
-  const int j = tid % BNP, osub = tid / BNP;
-  const int n_t = min(n0 + j, g.N - 1);
-  const int b_t = n_t / g.S_o, pix_t = n_t - b_t * g.S_o;
-  const int go_voff = ((b_t * g.O + osub * BPT) * g.S_o + pix_t) * 4;
-  const bool t_live = n0 + j < g.N;
-
-  const int T_o = bd.ochunks;                         // even
   const int passes = bd.cblks_q / (2 * WAVES_C);
   const int frag_bytes = 64 * 16;                      // one [lane][4] fragment
   const int chunk_bytes = bd.cblks_q * 2 * frag_bytes; // one ochunk of wq
   const rsrc_t r_in = make_rsrc(input, (size_t)g.B * g.C * g.S_i * 4);
-  const rsrc_t r_go = make_rsrc(gout, (size_t)g.B * g.O * g.S_o * 4);
   const rsrc_t r_wq = make_rsrc(wq, (size_t)g.K * T_o * chunk_bytes);
   const rsrc_t r_gc = make_rsrc(gcol, (size_t)g.B * g.C * g.K * g.S_o * 4);
   const int a_lane = lane * 16;
+  const float *Bb = Gs + (wp * 32 + (lane & 31)) * gpitch + 4 * kh;
+
+  auto a_base = [&](int tap, int pass) {
+    return tap * T_o * chunk_bytes + ((pass * WAVES_C + wc) * 2) * 2 * frag_bytes;
+  };
+  auto load_a = [&](float4 (&ra)[MB][2], int soff) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#ifdef ABL_BD_NOA
+        ra[i][q] = make_float4((float)soff, 1.f, 2.f, (float)a_lane);
+#else
+        ra[i][q] = buf_load4(r_wq, a_lane + (i * 2 + q) * frag_bytes, soff);
+#endif
+  };
+#ifdef ABL_BD_PRIO_STATIC
+  switch ((blockIdx.x >> 8) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); }
+#endif
+  float4 ra0[MB][2], ra1[MB][2];
+  load_a(ra0, a_base(0, 0));
+  __syncthreads();   // grad_out tile complete
 
   for (int tap = 0; tap < g.K; ++tap) {
     // ---- sampling state of (tap, this lane's pixel) ----
@@ -160,36 +201,22 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
 
     for (int pass = 0; pass < passes; ++pass) {
       const int cbase = (pass * WAVES_C + wc) * 64;       // this wave's 64 channels
-      const int a_soff0 = tap * T_o * chunk_bytes + (cbase / 32) * 2 * frag_bytes;
+      const int a_soff0 = a_base(tap, pass);
       f32x16 acc[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-      float rb[BPT];
-      auto load_b = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < BPT; ++i) rb[i] = buf_load(r_go, go_voff, (t * 16 + i) * g.S_o * 4);
-      };
-      auto commit_b = [&](float *Bb) {
-#pragma unroll
-        for (int i = 0; i < BPT; ++i) Bb[(osub * BPT + i) * BNP + j] = t_live ? rb[i] : 0.f;
-      };
-      auto load_a = [&](float4 (&ra)[MB][2], int t) {
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            ra[i][q] = buf_load4(r_wq, a_lane + (i * 2 + q) * frag_bytes, a_soff0 + t * chunk_bytes);
-      };
-      auto mma = [&](const float4 (&ra)[MB][2], const float *Bbuf) {
-        const float *Bb = Bbuf + wp * 32 + (lane & 31) + 4 * kh * BNP;
+      auto mma = [&](const float4 (&ra)[MB][2], const float *bp) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(bp);
+        const float4 b1 = *reinterpret_cast<const float4 *>(bp + 8);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const float b = Bb[(8 * q + s) * BNP];
+            const float4 bq = q == 0 ? b0 : b1;
+            const float b = s == 0 ? bq.x : (s == 1 ? bq.y : (s == 2 ? bq.z : bq.w));
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
               const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
@@ -198,23 +225,32 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
           }
       };
 
-      float4 ra0[MB][2], ra1[MB][2];
-      load_a(ra0, 0);
-      load_b(0);
+      // ra0 already holds chunk 0 of this (tap, pass)
+#if defined(ABL_BD_PRIO_EPI_HIGH)
+      __builtin_amdgcn_s_setprio(0);
+#elif defined(ABL_BD_PRIO_EPI_LOW)
+      __builtin_amdgcn_s_setprio(3);
+#endif
       for (int t = 0; t < T_o; t += 2) {
-        commit_b(smem);
-        __syncthreads();
-        load_b(t + 1);
-        load_a(ra1, t + 1);
+        load_a(ra1, a_soff0 + (t + 1) * chunk_bytes);
         __builtin_amdgcn_sched_barrier(0);
-        mma(ra0, smem);
-        commit_b(smem + BK * BNP);
-        __syncthreads();
-        const int tn = min(t + 2, T_o - 1);
-        load_b(tn);
-        load_a(ra0, tn);
+#ifndef ABL_BD_NOMFMA
+        mma(ra0, Bb + t * 16);
+#endif
+        load_a(ra0, a_soff0 + min(t + 2, T_o - 1) * chunk_bytes);
         __builtin_amdgcn_sched_barrier(0);
-        mma(ra1, smem + BK * BNP);
+        mma(ra1, Bb + (t + 1) * 16);
+      }
+#if defined(ABL_BD_PRIO_EPI_HIGH)
+      __builtin_amdgcn_s_setprio(3);
+#elif defined(ABL_BD_PRIO_EPI_LOW)
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      // first A chunk of the next (tap, pass): in flight during the epilogue
+      {
+        int ntap = tap, npass = pass + 1;
+        if (npass == passes) { npass = 0; ntap = min(tap + 1, g.K - 1); }
+        load_a(ra0, a_base(ntap, npass));
       }
 
       // ---- epilogue of (tap, pass): lane = pixel, acc rows = channels ----
@@ -232,22 +268,17 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
             const int cu = cbase + mb * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh is in the voffset
             const int cs = min(cu, g.C - 5) * g.S_i * 4;   // cu % 8 < 4, so C-5 is the last valid one
 #pragma unroll
+#ifdef ABL_BD_NOGATHER
+            for (int pi = 0; pi < NP; ++pi) vb[rr][pi] = make_float2(w[0], (float)cs);
+#else
             for (int pi = 0; pi < NP; ++pi) vb[rr][pi] = buf_load2(r_in, voff[pi], cs);
+#endif
           }
         };
-#ifdef ABL_SINGLEBUF
-#define VB(k) 0
-#else
-#define VB(k) ((k) & 1)
         gather_batch(v[0], 0);
-#endif
 #pragma unroll
         for (int k = 0; k < NBATCH; ++k) {
-#ifdef ABL_SINGLEBUF
-          gather_batch(v[0], k);
-#else
           if (k + 1 < NBATCH) gather_batch(v[(k + 1) & 1], k + 1);
-#endif
           asm volatile("" ::: "memory");   // IR-level fence: later gathers must not be hoisted here
           __builtin_amdgcn_sched_barrier(0);
           const int mb = (k * RB) / 16, r0 = (k * RB) % 16;
@@ -259,7 +290,15 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
           for (int gq = 0; gq < RB / 4; ++gq) {
             const int cu4 = cbase + mb * 32 + 8 * ((r0 >> 2) + gq);
             const int vo = (live && cu4 < g.C) ? gc_voff : (int)0x7ffffff0;
-            buf_store4(r_gc, vo, cu4 * 4, acc[mb][r0 + 4 * gq], acc[mb][r0 + 4 * gq + 1],
+#ifdef ABL_BD_NOSTORE
+            if (acc[mb][r0 + 4 * gq] == 123.456f)
+#endif
+#ifdef ABL_BD_NT
+            buf_store4<2>
+#else
+            buf_store4
+#endif
+                      (r_gc, vo, cu4 * 4, acc[mb][r0 + 4 * gq], acc[mb][r0 + 4 * gq + 1],
                        acc[mb][r0 + 4 * gq + 2], acc[mb][r0 + 4 * gq + 3]);
           }
           // padded channels have grad_col == 0 exactly (zero weight rows), no predicate needed
@@ -268,8 +307,8 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
             const float gc = acc[mb][r0 + rr];
 #pragma unroll
             for (int pi = 0; pi < NP; ++pi) {
-              S[2 * pi] = fmaf(gc, v[VB(k)][rr][pi].x, S[2 * pi]);
-              S[2 * pi + 1] = fmaf(gc, v[VB(k)][rr][pi].y, S[2 * pi + 1]);
+              S[2 * pi] = fmaf(gc, v[k & 1][rr][pi].x, S[2 * pi]);
+              S[2 * pi + 1] = fmaf(gc, v[k & 1][rr][pi].y, S[2 * pi + 1]);
             }
           }
 #pragma unroll
@@ -283,43 +322,43 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
     float goff[ND], gm = 0.f;
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) gm = fmaf(w[ci], S[ci], gm);
+    const float mg = (!g.range_gate || inside) ? m : 0.f;
 #pragma unroll
     for (int a = 0; a < ND; ++a) {
       goff[a] = 0.f;
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci) goff[a] = fmaf(dw[a][ci], S[ci], goff[a]);
+      goff[a] *= mg;
     }
-    // ---- reduce over channels: the two half-waves, then the WAVES_C channel-waves ----
+    // ---- reduce over channels: the two half-waves here, the WAVES_C channel-waves at the flush ----
 #pragma unroll
     for (int a = 0; a < ND; ++a) goff[a] += __shfl_xor(goff[a], 32, 64);
     gm += __shfl_xor(gm, 32, 64);
-    if (WAVES_C > 1) {
-      __syncthreads();   // every wave is done with the LDS slabs of this tap
-      float *red = smem;   // [WAVES_C][ND + 1][BNP]
-      if (kh == 0 && wc > 0) {
+    const int slot = tap % kTapGroup;
+    if (kh == 0) {
+      float *rp = red + ((slot * WAVES_C + wc) * (ND + 1)) * BNP + wp * 32 + lane;
 #pragma unroll
-        for (int a = 0; a < ND; ++a) red[(wc * (ND + 1) + a) * BNP + wp * 32 + lane] = goff[a];
-        red[(wc * (ND + 1) + ND) * BNP + wp * 32 + lane] = gm;
-      }
+      for (int a = 0; a < ND; ++a) rp[a * BNP] = goff[a];
+      rp[ND * BNP] = gm;
+    }
+    if (slot == kTapGroup - 1 || tap == g.K - 1) {
       __syncthreads();
-      if (kh == 0 && wc == 0) {
+      // single owner of every (b, tap, pix): plain accumulate (the C ABI accumulates into grads)
+      const int tap0 = tap - slot;
+      const int items = (slot + 1) * (ND + 1) * BNP;
+      for (int it = tid; it < items; it += 256) {
+        const int jj = it % BNP, a = (it / BNP) % (ND + 1), sl = it / (BNP * (ND + 1));
+        const int n = n0 + jj;
+        if (n < g.N && (MOD || a < ND)) {
+          float sum = 0.f;
 #pragma unroll
-        for (int x = 1; x < WAVES_C; ++x) {
-#pragma unroll
-          for (int a = 0; a < ND; ++a) goff[a] += red[(x * (ND + 1) + a) * BNP + wp * 32 + lane];
-          gm += red[(x * (ND + 1) + ND) * BNP + wp * 32 + lane];
+          for (int x = 0; x < WAVES_C; ++x) sum += red[((sl * WAVES_C + x) * (ND + 1) + a) * BNP + jj];
+          const int b = n / g.S_o, pix = n - b * g.S_o, tp = tap0 + sl;
+          if (a < ND) grad_offset[((int64_t)b * (ND * g.K) + ND * tp + a) * g.S_o + pix] += sum;
+          else grad_mask[((int64_t)b * g.K + tp) * g.S_o + pix] += sum;
         }
       }
-      __syncthreads();   // red is overwritten by the next tap's first slab
-    }
-    if (kh == 0 && wc == 0 && live) {
-      // single owner of (b, tap, pix): plain accumulate (the C ABI accumulates into grads)
-      if (!g.range_gate || inside) {
-        const int64_t ob = ((int64_t)b_l * (ND * g.K) + ND * tap) * g.S_o + pix_l;
-#pragma unroll
-        for (int a = 0; a < ND; ++a) grad_offset[ob + (int64_t)a * g.S_o] += goff[a] * m;
-      }
-      if (MOD) grad_mask[((int64_t)b_l * g.K + tap) * g.S_o + pix_l] += gm;
+      __syncthreads();
     }
   }
 }
@@ -485,13 +524,24 @@ int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq
   return check_launch("pack_wq");
 }
 
+size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
+  const int bnp = 32 * (4 / bd.waves_c);
+  return ((size_t)bnp * (bd.ochunks * 16 + 4) + (size_t)kTapGroup * 128 * (g.nd + 1)) * sizeof(float);
+}
+
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, hipStream_t stream) {
 #define LAUNCH_BD(ND, MOD, WC)                                                                  \
   do {                                                                                          \
     const int bnp = 32 * (4 / WC);                                                              \
     const int ntiles = (g.N + bnp - 1) / bnp;                                                   \
-    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC>), dim3(ntiles), dim3(256), 0, stream, \
+    const size_t lds = bwd_data_lds_bytes(g, bd);                                               \
+    if (lds > 64 * 1024) {                                                                      \
+      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC>,      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; } \
+    }                                                                                           \
+    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC>), dim3(ntiles), dim3(256), lds, stream, \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
                        (float *)t.grad_offset, (float *)t.grad_mask, ntiles);                   \

@@ -86,6 +86,7 @@ BwdDims bwd_dims(const Geom &g) {
   bd.splits = (pairs + bd.pairs_per_split - 1) / bd.pairs_per_split;
   bd.ochunks = (g.O + 31) / 32 * 2;
   bd.waves_c = g.C > 128 ? 4 : (g.C > 64 ? 2 : 1);
+  if (const char *e = getenv("MDCONV_BD_WAVES_C")) bd.waves_c = atoi(e);   // experiments
   bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
   const int nc = 1 << g.nd;
   size_t off = 0;
@@ -252,6 +253,7 @@ bool mfma_supported(const Geom &g, int dtype, bool backward) {
   if (g.in_sz[g.nd - 1] < 2) return false;   // paired-corner gathers need 2 columns
   if (!(g.DG == 1 || (g.Cdg % (2 * kBK) == 0 && g.Cg % (2 * kBK) == 0))) return false;
   if (backward && (g.G != 1 || g.DG != 1 || g.C % 8)) return false;
+  if (backward && bwd_data_lds_bytes(g, bwd_dims(g)) > 150 * 1024) return false;   // grad_out tile lives in LDS
   Plan p;
   return make_plan(g, dtype, backward, &p);   // one image must fit 32-bit buffer offsets
 }

@@ -59,12 +59,13 @@ __device__ __forceinline__ float4 buf_load4(rsrc_t r, int voff, int soff) {
   return make_float4(f.x, f.y, f.z, f.w);
 }
 
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store4(rsrc_t r, int voff, int soff, float a, float b, float c,
                                            float d) {
   typedef unsigned int u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
   const u32x4 v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
                    __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, AUX);   // AUX 2 = nt (streaming)
 }
 
 // Dimensions / workspace layout of the MFMA backward (fp32, groups == 1).
@@ -99,6 +100,7 @@ int pack_gout_f32(const Geom &g, const BwdDims &bd, const float *gout, float *ga
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, hipStream_t stream);
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);
+size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, hipStream_t stream);
 int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol, int *cnt,
