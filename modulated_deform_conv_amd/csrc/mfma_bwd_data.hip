@@ -27,6 +27,7 @@
 //     per-lane list walks took 3.5 ms at cfg2; this one is HBM-bound.)
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
+#include <algorithm>
 
 namespace mdconv {
 
@@ -65,65 +66,76 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
 // ---------------------------------------------------------------------------------------------
 // 1. GEMM-1 + coordinate gradients + grad_col stream
 // ---------------------------------------------------------------------------------------------
-// The grad_out tile of the workgroup ([C_out] x BNP pixels, 32 KB at cfg2) does not depend on the
-// tap, so it is loaded into LDS ONCE, o-innermost, and the K loops of all taps read their B
-// fragments from it with two ds_read_b128 per 16 MFMAs: no global B loads, no LDS writes and no
-// barriers inside the tap loop, so the four waves drift apart and one wave's gather epilogue
-// overlaps the others' MFMAs.  The per-tap channel reduction goes through a small LDS buffer
-// that is flushed every kTapGroup taps (the only barriers left).
+// Work decomposition: a UNIT is one (pixel tile, tap); a workgroup walks a contiguous unit range.
+// The first n_full workgroups (a whole number of dispatch rounds, 2 workgroups per CU) take one
+// tile = K units each; the units of the leftover tiles are spread evenly over one last round of
+// short workgroups.  (With one workgroup per tile, cfg2's 3136 tiles over 512 slots left the
+// seventh round 1/8 full: ~12 % of the kernel.  A fully persistent grid -- one long unit range
+// per slot -- was measured 25 % SLOWER: every workgroup then runs in phase with every other and
+// they all hit the same few L2 channels at the same time.)  A tile split between workgroups
+// needs no atomics: grad_col, grad_offset and grad_mask are all per-tap outputs.
+//
+// The grad_out tile ([C_out] x BNP pixels, 32 KB at cfg2) does not depend on the tap, so it is
+// loaded into LDS once per tile, o-innermost, and the K loops of all taps read their B fragments
+// from it with two ds_read_b128 per 16 MFMAs: no global B loads, LDS writes or barriers inside
+// the tap loop.
+//
+// Software pipeline inside every wave: the epilogue of iteration i-1 (corner gathers, grad_col
+// stores, the corner sums) is DRAINED while the K loop of iteration i runs -- the accumulators of
+// i-1 are parked in a second register set.  (A separate epilogue phase added its full latency to
+// the kernel: co-resident waves run in lockstep, "another wave covers it" did not happen.)  The
+// drain is cut into NBATCH batches (RB accumulator rows each); batch q is gathered at the start
+// of the q-th part of the K loop and consumed at its end.  A fragments are prefetched three
+// chunks ahead so that the MFMAs issued right after a batch of gathers only wait for loads OLDER
+// than the gathers (vmcnt retires in order).
+//
+// QPQ > 0: the K loop has exactly QPQ * NBATCH quads (4 chunks each) and is emitted as
+// straight-line code; QPQ == 0: any shape, runtime loops.
 constexpr int kTapGroup = 9;
 
-template <int ND, bool MOD, int WAVES_C>
-__global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
+template <int ND, bool MOD, int WAVES_C, int QPQ>
+__global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
-    int ntiles) {
+    int ntiles, int n_full, int n_tail) {
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
-  constexpr int BNP = 32 * WAVES_P;        // pixels per workgroup
-  constexpr int RB = 8;                    // accumulator rows gathered per batch
+  constexpr int BNP = 32 * WAVES_P;        // pixels per tile
+  constexpr int RB = ND == 2 ? 8 : 4;      // accumulator rows per drain batch
+  constexpr int NBATCH = MB * 16 / RB;
+  constexpr int kOob = 0x7ffffff0;         // out-of-range buffer offset: loads give 0, stores drop
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int T_o = bd.ochunks;              // even
+  const int T_o = bd.ochunks;              // multiple of 4
   const int gpitch = T_o * 16 + 4;         // floats per pixel row of the grad_out tile
   float *Gs = smem;                        // [BNP][gpitch]
   float *red = smem + BNP * gpitch;        // [kTapGroup][WAVES_C][ND + 1][BNP]
 
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int n0 = tile * BNP;
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
   // wave id as an SGPR: anything derived from threadIdx is 'divergent' to hipcc, and a divergent
   // buffer soffset is wrapped in a readfirstlane waterfall per load (cdna_hip_programming.md T20)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WAVES_P, wp = wave % WAVES_P;
 
-  // ---- grad_out tile -> LDS (once) ----
-  {
-    const int j = tid % BNP, osub = tid / BNP;
-    constexpr int OSTEP = 256 / BNP;
-    const int n_t = min(n0 + j, g.N - 1);
-    const int b_t = n_t / g.S_o, pix_t = n_t - b_t * g.S_o;
-    const bool t_live = n0 + j < g.N;
-    const float *src = gout + ((int64_t)b_t * g.O) * g.S_o + pix_t;
-    float *dst = Gs + j * gpitch;
-    const int Opad = T_o * 16;
-#pragma unroll 8
-    for (int o = osub; o < Opad; o += OSTEP) {
-      const float v = src[(int64_t)min(o, g.O - 1) * g.S_o];
-      dst[o] = (t_live && o < g.O) ? v : 0.f;
-    }
+  // unit range of this workgroup: the first n_full workgroups take one whole tile each (complete
+  // dispatch rounds), the last n_tail share the units of the remaining tiles evenly.
+  // Neighbouring ranges share an XCD, hence an L2.
+  int u0, u1;
+  if ((int)blockIdx.x < n_full) {
+    u0 = xcd_remap(blockIdx.x, n_full) * g.K;
+    u1 = u0 + g.K;
+  } else {
+    const int j = xcd_remap(blockIdx.x - n_full, n_tail);
+    const int64_t tail_units = (int64_t)(ntiles - n_full) * g.K;
+    u0 = n_full * g.K + (int)(tail_units * j / n_tail);
+    u1 = n_full * g.K + (int)(tail_units * (j + 1) / n_tail);
   }
-
-  // the pixel this lane owns in the accumulator layout
-  const int n_raw = n0 + wp * 32 + (lane & 31);
-  const bool live = n_raw < g.N;
-  const int n_l = live ? n_raw : g.N - 1;
-  const int b_l = n_l / g.S_o, pix_l = n_l - b_l * g.S_o;
-  int oc[ND];
-  out_coords<ND>(g, pix_l, oc);
+  if (u0 >= u1) return;
 
   const int passes = bd.cblks_q / (2 * WAVES_C);
+  const int iters = (u1 - u0) * passes;
+  const int nquads = T_o / 4;
   const int frag_bytes = 64 * 16;                      // one [lane][4] fragment
   const int chunk_bytes = bd.cblks_q * 2 * frag_bytes; // one ochunk of wq
   const rsrc_t r_in = make_rsrc(input, (size_t)g.B * g.C * g.S_i * 4);
@@ -132,197 +144,162 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
   const int a_lane = lane * 16;
   const float *Bb = Gs + (wp * 32 + (lane & 31)) * gpitch + 4 * kh;
 
-  auto a_base = [&](int tap, int pass) {
-    return tap * T_o * chunk_bytes + ((pass * WAVES_C + wc) * 2) * 2 * frag_bytes;
+  // byte offset of A chunk t of (tap, pass); t >= T_o runs on into the following (tap, pass)
+  auto a_off = [&](int tap, int pass, int t) {
+    if (t >= T_o) {
+      t -= T_o;
+      if (++pass == passes) { pass = 0; tap = tap + 1 == g.K ? 0 : tap + 1; }
+    }
+    return (tap * T_o + t) * chunk_bytes + ((pass * WAVES_C + wc) * 2) * 2 * frag_bytes;
   };
   auto load_a = [&](float4 (&ra)[MB][2], int soff) {
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int q = 0; q < 2; ++q)
-#ifdef ABL_BD_NOA
-        ra[i][q] = make_float4((float)soff, 1.f, 2.f, (float)a_lane);
-#else
         ra[i][q] = buf_load4(r_wq, a_lane + (i * 2 + q) * frag_bytes, soff);
-#endif
   };
-#ifdef ABL_BD_PRIO_STATIC
-  switch ((blockIdx.x >> 8) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); }
-#endif
-  float4 ra0[MB][2], ra1[MB][2];
-  load_a(ra0, a_base(0, 0));
-  __syncthreads();   // grad_out tile complete
+  float4 ra0[MB][2], ra1[MB][2], ra2[MB][2], ra3[MB][2];
+  {
+    const int tap_first = u0 % g.K;
+    load_a(ra0, a_off(tap_first, 0, 0));
+    load_a(ra1, a_off(tap_first, 0, 1));
+    load_a(ra2, a_off(tap_first, 0, 2));
+  }
 
-  for (int tap = 0; tap < g.K; ++tap) {
-    // ---- sampling state of (tap, this lane's pixel) ----
-    // corner PAIRS (make_pairs): byte offsets, value weights and d/dp weights of both elements
-    int voff[NP];
-    float w[NC], dw[ND][NC];
-    float m = 1.f;
-    bool inside;
-    {
-      float delta[ND];
-      const int64_t ob = ((int64_t)b_l * (ND * g.K) + ND * tap) * g.S_o + pix_l;
+  // ---- the pixel this lane owns in the accumulator layout: of the tile whose K loop runs
+  // (`c`) and of the tile whose accumulators are parked (`p`) ----
+  struct Pix { int n0, b, pix; bool live; int oc[ND]; };
+  auto pix_of_tile = [&](int tile, Pix &px) {
+    px.n0 = tile * BNP;
+    const int n_raw = px.n0 + wp * 32 + (lane & 31);
+    px.live = n_raw < g.N;
+    const int n_l = px.live ? n_raw : g.N - 1;
+    px.b = n_l / g.S_o;
+    px.pix = n_l - px.b * g.S_o;
+    out_coords<ND>(g, px.pix, px.oc);
+  };
+  Pix pc, pp;
+  pix_of_tile(u0 / g.K, pc);
+  pp = pc;
+
+  // ---- grad_out tile -> LDS ----
+  auto load_gout_tile = [&](int tile) {
+    const int j = tid % BNP, osub = tid / BNP;
+    constexpr int OSTEP = 256 / BNP;
+    const int n_t = min(tile * BNP + j, g.N - 1);
+    const int b_t = n_t / g.S_o, pix_t = n_t - b_t * g.S_o;
+    const bool t_live = tile * BNP + j < g.N;
+    const float *src = gout + ((int64_t)b_t * g.O) * g.S_o + pix_t;
+    float *dst = Gs + j * gpitch;
+    const int Opad = T_o * 16;
+#pragma unroll 8
+    for (int o = osub; o < Opad; o += OSTEP) {
+      const float v = src[(int64_t)min(o, g.O - 1) * g.S_o];
+      dst[o] = (t_live && o < g.O) ? v : 0.f;
+    }
+  };
+
+  // sampling state of the tap being drained; before the first drain every gather / store goes
+  // out of range and the parked accumulators are 0
+  int voff[NP], gc_voff = kOob;
+  float w[NC], dw[ND][NC], mg = 0.f;
+  float S[NC];
+  float delta_n[ND], m_n = 1.f;   // raw offset / mask of the unit whose K loop is running
+  f32x16 acc[MB], accp[MB];
 #pragma unroll
-      for (int a = 0; a < ND; ++a) delta[a] = offset[ob + (int64_t)a * g.S_o];
-      int tcd[ND];
-      tap_coords<ND>(g, tap, tcd);
-      TapCoef<ND, float> tc;
-      make_tap<ND, float>(g, oc, tcd, delta, true, tc);
-      if (MOD) m = mask[((int64_t)b_l * g.K + tap) * g.S_o + pix_l];
-      inside = tc.inside;
-      int pidx[NP];
-      float px[NP], py[NP];
-      make_pairs<ND, float>(g, tc, 1.f, pidx, px, py);
+  for (int pi = 0; pi < NP; ++pi) voff[pi] = kOob;
+#pragma unroll
+  for (int ci = 0; ci < NC; ++ci) { S[ci] = 0.f; w[ci] = 0.f; }
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    delta_n[a] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) dw[a][ci] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[i][r] = 0.f;
+
+  // ---- sampling state of (tapp, parked pixel): corner PAIRS (make_pairs) ----
+  auto new_tap_state = [&](int tapp) {
+    int tcd[ND];
+    tap_coords<ND>(g, tapp, tcd);
+    TapCoef<ND, float> tc;
+    make_tap<ND, float>(g, pp.oc, tcd, delta_n, true, tc);
+    mg = (!g.range_gate || tc.inside) ? m_n : 0.f;
+    int pidx[NP];
+    float px[NP], py[NP];
+    make_pairs<ND, float>(g, tc, 1.f, pidx, px, py);
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+      voff[pi] = (pp.b * g.C * g.S_i + pidx[pi] + 4 * kh * g.S_i) * 4;
+      w[2 * pi] = px[pi];
+      w[2 * pi + 1] = py[pi];
+    }
+#pragma unroll
+    for (int a = 0; a < ND; ++a) {
+      make_pairs_d<ND, float>(g, tc, a, px, py);
 #pragma unroll
       for (int pi = 0; pi < NP; ++pi) {
-        voff[pi] = (b_l * g.C * g.S_i + pidx[pi] + 4 * kh * g.S_i) * 4;
-        w[2 * pi] = px[pi];
-        w[2 * pi + 1] = py[pi];
-      }
-#pragma unroll
-      for (int a = 0; a < ND; ++a) {
-        make_pairs_d<ND, float>(g, tc, a, px, py);
-#pragma unroll
-        for (int pi = 0; pi < NP; ++pi) {
-          dw[a][2 * pi] = px[pi];
-          dw[a][2 * pi + 1] = py[pi];
-        }
+        dw[a][2 * pi] = px[pi];
+        dw[a][2 * pi + 1] = py[pi];
       }
     }
-    const int gc_voff = ((((b_l * g.K + tap) * g.S_o + pix_l) * g.C) + 4 * kh) * 4;
-    // S[e] = sum over this lane's channels of grad_col * (element e of the corner pairs).  The corner weights and
-    // their derivatives do not depend on the channel, so the epilogue costs 2^ND FMAs per channel
-    // and grad_mask / grad_offset are recovered from S once per tap:
+    gc_voff = pp.live ? ((((pp.b * g.K + tapp) * g.S_o + pp.pix) * g.C) + 4 * kh) * 4 : kOob;
+    // S[e] = sum over this lane's channels of grad_col * (element e of the corner pairs).  The
+    // corner weights and their derivatives do not depend on the channel, so the drain costs
+    // 2^ND FMAs per channel and grad_mask / grad_offset are recovered from S once per tap:
     //   grad_mask += sum_ci w[ci] S[ci],   grad_offset_a += m * sum_ci dw[a][ci] S[ci].
-    float S[NC];
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) S[ci] = 0.f;
+  };
 
-    for (int pass = 0; pass < passes; ++pass) {
-      const int cbase = (pass * WAVES_C + wc) * 64;       // this wave's 64 channels
-      const int a_soff0 = a_base(tap, pass);
-      f32x16 acc[MB];
+  // ---- drain batch q of the parked accumulators (channels cbase_p ..): gather, then consume ----
+  auto gather = [&](int q, int cbase_p, float2 (&v)[RB][NP]) {
+    const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
 #pragma unroll
-      for (int i = 0; i < MB; ++i)
+    for (int rr = 0; rr < RB; ++rr) {
+      const int r = r0 + rr;
+      const int cu = cbase_p + mb * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh is in the voffset
+      const int cs = min(cu, g.C - 5) * g.S_i * 4;   // cu % 8 < 4, so C-5 is the last valid one
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-      auto mma = [&](const float4 (&ra)[MB][2], const float *bp) {
-        const float4 b0 = *reinterpret_cast<const float4 *>(bp);
-        const float4 b1 = *reinterpret_cast<const float4 *>(bp + 8);
+      for (int pi = 0; pi < NP; ++pi) v[rr][pi] = buf_load2(r_in, voff[pi], cs);
+    }
+  };
+  auto consume = [&](int q, int cbase_p, const float2 (&v)[RB][NP]) {
+    const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
+    // grad_col[b][tap][pix][c]: rows r0+4g .. r0+4g+3 are 4 consecutive channels.  Dead lanes
+    // and padded channels store to an out-of-range offset, which the bounds check drops.
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+    for (int gq = 0; gq < RB / 4; ++gq) {
+      const int cu4 = cbase_p + mb * 32 + 8 * ((r0 >> 2) + gq);
+      const int vo = cu4 < g.C ? gc_voff : kOob;
+      buf_store4(r_gc, vo, cu4 * 4, accp[mb][r0 + 4 * gq], accp[mb][r0 + 4 * gq + 1],
+                 accp[mb][r0 + 4 * gq + 2], accp[mb][r0 + 4 * gq + 3]);
+    }
+    // padded channels have grad_col == 0 exactly (zero weight rows), no predicate needed
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const float4 bq = q == 0 ? b0 : b1;
-            const float b = s == 0 ? bq.x : (s == 1 ? bq.y : (s == 2 ? bq.z : bq.w));
+    for (int rr = 0; rr < RB; ++rr) {
+      const float gc = accp[mb][r0 + rr];
 #pragma unroll
-            for (int i = 0; i < MB; ++i) {
-              const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
-              acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-            }
-          }
-      };
-
-      // ra0 already holds chunk 0 of this (tap, pass)
-#if defined(ABL_BD_PRIO_EPI_HIGH)
-      __builtin_amdgcn_s_setprio(0);
-#elif defined(ABL_BD_PRIO_EPI_LOW)
-      __builtin_amdgcn_s_setprio(3);
-#endif
-      for (int t = 0; t < T_o; t += 2) {
-        load_a(ra1, a_soff0 + (t + 1) * chunk_bytes);
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef ABL_BD_NOMFMA
-        mma(ra0, Bb + t * 16);
-#endif
-        load_a(ra0, a_soff0 + min(t + 2, T_o - 1) * chunk_bytes);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ra1, Bb + (t + 1) * 16);
-      }
-#if defined(ABL_BD_PRIO_EPI_HIGH)
-      __builtin_amdgcn_s_setprio(3);
-#elif defined(ABL_BD_PRIO_EPI_LOW)
-      __builtin_amdgcn_s_setprio(0);
-#endif
-      // first A chunk of the next (tap, pass): in flight during the epilogue
-      {
-        int ntap = tap, npass = pass + 1;
-        if (npass == passes) { npass = 0; ntap = min(tap + 1, g.K - 1); }
-        load_a(ra0, a_base(ntap, npass));
-      }
-
-      // ---- epilogue of (tap, pass): lane = pixel, acc rows = channels ----
-      // Rows are processed in batches of RB; the corner gathers of batch k+1 are in flight while
-      // batch k is consumed (sched_barriers keep hipcc from hoisting every gather to the top,
-      // which cost 284 VGPRs and occupancy 1).
-      if (cbase < g.C) {
-        constexpr int NBATCH = MB * 16 / RB;
-        float2 v[2][RB][NP];
-        auto gather_batch = [&](float2 (&vb)[RB][NP], int k) {
-          const int mb = (k * RB) / 16, r0 = (k * RB) % 16;
-#pragma unroll
-          for (int rr = 0; rr < RB; ++rr) {
-            const int r = r0 + rr;
-            const int cu = cbase + mb * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh is in the voffset
-            const int cs = min(cu, g.C - 5) * g.S_i * 4;   // cu % 8 < 4, so C-5 is the last valid one
-#pragma unroll
-#ifdef ABL_BD_NOGATHER
-            for (int pi = 0; pi < NP; ++pi) vb[rr][pi] = make_float2(w[0], (float)cs);
-#else
-            for (int pi = 0; pi < NP; ++pi) vb[rr][pi] = buf_load2(r_in, voff[pi], cs);
-#endif
-          }
-        };
-        gather_batch(v[0], 0);
-#pragma unroll
-        for (int k = 0; k < NBATCH; ++k) {
-          if (k + 1 < NBATCH) gather_batch(v[(k + 1) & 1], k + 1);
-          asm volatile("" ::: "memory");   // IR-level fence: later gathers must not be hoisted here
-          __builtin_amdgcn_sched_barrier(0);
-          const int mb = (k * RB) / 16, r0 = (k * RB) % 16;
-          // grad_col[b][tap][pix][c]: rows r0+4g .. r0+4g+3 are 4 consecutive channels.  No
-          // branches here (they would split the block and let hipcc sink the S updates below all
-          // four batches, keeping 128 gathered values live): dead lanes / padded channels store to
-          // an out-of-range offset, which the buffer bounds check drops.
-#pragma unroll
-          for (int gq = 0; gq < RB / 4; ++gq) {
-            const int cu4 = cbase + mb * 32 + 8 * ((r0 >> 2) + gq);
-            const int vo = (live && cu4 < g.C) ? gc_voff : (int)0x7ffffff0;
-#ifdef ABL_BD_NOSTORE
-            if (acc[mb][r0 + 4 * gq] == 123.456f)
-#endif
-#ifdef ABL_BD_NT
-            buf_store4<2>
-#else
-            buf_store4
-#endif
-                      (r_gc, vo, cu4 * 4, acc[mb][r0 + 4 * gq], acc[mb][r0 + 4 * gq + 1],
-                       acc[mb][r0 + 4 * gq + 2], acc[mb][r0 + 4 * gq + 3]);
-          }
-          // padded channels have grad_col == 0 exactly (zero weight rows), no predicate needed
-#pragma unroll
-          for (int rr = 0; rr < RB; ++rr) {
-            const float gc = acc[mb][r0 + rr];
-#pragma unroll
-            for (int pi = 0; pi < NP; ++pi) {
-              S[2 * pi] = fmaf(gc, v[k & 1][rr][pi].x, S[2 * pi]);
-              S[2 * pi + 1] = fmaf(gc, v[k & 1][rr][pi].y, S[2 * pi + 1]);
-            }
-          }
-#pragma unroll
-          for (int ci = 0; ci < NC; ++ci) asm volatile("" : "+v"(S[ci]));   // pin the updates here
-          asm volatile("" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int pi = 0; pi < NP; ++pi) {
+        S[2 * pi] = fmaf(gc, v[rr][pi].x, S[2 * pi]);
+        S[2 * pi + 1] = fmaf(gc, v[rr][pi].y, S[2 * pi + 1]);
       }
     }
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) asm volatile("" : "+v"(S[ci]));   // pin the updates here
+  };
 
+  // ---- tap `tapp` of the parked tile is complete for this wave's channels: reduce, park in
+  // LDS; `flush` (end of a tap group / of the tile / of the unit range) writes the group out ----
+  int grp_lo = (u0 % g.K) % kTapGroup;   // first slot of the current tap group held in `red`
+  auto finish_tap = [&](int tapp, bool last) {
     float goff[ND], gm = 0.f;
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) gm = fmaf(w[ci], S[ci], gm);
-    const float mg = (!g.range_gate || inside) ? m : 0.f;
 #pragma unroll
     for (int a = 0; a < ND; ++a) {
       goff[a] = 0.f;
@@ -330,36 +307,140 @@ __global__ __launch_bounds__(256, 3) void mfma_bwd_data_kernel(
       for (int ci = 0; ci < NC; ++ci) goff[a] = fmaf(dw[a][ci], S[ci], goff[a]);
       goff[a] *= mg;
     }
-    // ---- reduce over channels: the two half-waves here, the WAVES_C channel-waves at the flush ----
+    // reduce over channels: the two half-waves here, the WAVES_C channel-waves at the flush
 #pragma unroll
     for (int a = 0; a < ND; ++a) goff[a] += __shfl_xor(goff[a], 32, 64);
     gm += __shfl_xor(gm, 32, 64);
-    const int slot = tap % kTapGroup;
+    const int slot = tapp % kTapGroup;
     if (kh == 0) {
       float *rp = red + ((slot * WAVES_C + wc) * (ND + 1)) * BNP + wp * 32 + lane;
 #pragma unroll
       for (int a = 0; a < ND; ++a) rp[a * BNP] = goff[a];
       rp[ND * BNP] = gm;
     }
-    if (slot == kTapGroup - 1 || tap == g.K - 1) {
+    if (slot == kTapGroup - 1 || tapp == g.K - 1 || last) {
       __syncthreads();
       // single owner of every (b, tap, pix): plain accumulate (the C ABI accumulates into grads)
-      const int tap0 = tap - slot;
-      const int items = (slot + 1) * (ND + 1) * BNP;
-      for (int it = tid; it < items; it += 256) {
-        const int jj = it % BNP, a = (it / BNP) % (ND + 1), sl = it / (BNP * (ND + 1));
-        const int n = n0 + jj;
+      const int tap0 = tapp - slot;
+      const int items = (slot + 1 - grp_lo) * (ND + 1) * BNP;
+      for (int x = tid; x < items; x += 256) {
+        const int jj = x % BNP, a = (x / BNP) % (ND + 1), sl = grp_lo + x / (BNP * (ND + 1));
+        const int n = pp.n0 + jj;
         if (n < g.N && (MOD || a < ND)) {
           float sum = 0.f;
 #pragma unroll
-          for (int x = 0; x < WAVES_C; ++x) sum += red[((sl * WAVES_C + x) * (ND + 1) + a) * BNP + jj];
+          for (int y = 0; y < WAVES_C; ++y) sum += red[((sl * WAVES_C + y) * (ND + 1) + a) * BNP + jj];
           const int b = n / g.S_o, pix = n - b * g.S_o, tp = tap0 + sl;
           if (a < ND) grad_offset[((int64_t)b * (ND * g.K) + ND * tp + a) * g.S_o + pix] += sum;
           else grad_mask[((int64_t)b * g.K + tp) * g.S_o + pix] += sum;
         }
       }
       __syncthreads();
+      grp_lo = 0;   // the next group starts at its first slot (a new tile starts at tap 0)
     }
+  };
+
+  auto mma = [&](const float4 (&ra)[MB][2], const float *bp) {
+    const float4 b0 = *reinterpret_cast<const float4 *>(bp);
+    const float4 b1 = *reinterpret_cast<const float4 *>(bp + 8);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4 bq = q == 0 ? b0 : b1;
+        const float b = s == 0 ? bq.x : (s == 1 ? bq.y : (s == 2 ? bq.z : bq.w));
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+      }
+  };
+  // four chunks t .. t+3 of (tap, pass); A runs three chunks ahead (into the next iteration).
+  // (Fetching the B fragments a chunk ahead as well was measured slower: 1.24 -> 1.30 ms.)
+  auto quad = [&](int tap, int pass, int t) {
+    load_a(ra3, a_off(tap, pass, t + 3));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(ra0, Bb + t * 16);
+    load_a(ra0, a_off(tap, pass, t + 4));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(ra1, Bb + (t + 1) * 16);
+    load_a(ra1, a_off(tap, pass, t + 5));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(ra2, Bb + (t + 2) * 16);
+    load_a(ra2, a_off(tap, pass, t + 6));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(ra3, Bb + (t + 3) * 16);
+  };
+
+  int tile_c = -1;   // tile whose grad_out is in LDS
+  int tapp = 0, passp = 0;   // (tap, pass) of the parked accumulators
+  int tile = u0 / g.K, tap = u0 - tile * g.K, pass = 0;   // of the running K loop
+  for (int it = 0; it < iters; ++it) {
+    if (it > 0 && passp == 0) new_tap_state(tapp);
+    if (tile != tile_c) {
+      if (tile_c >= 0) __syncthreads();   // every wave is done with the previous tile's K loops
+      load_gout_tile(tile);
+      pix_of_tile(tile, pc);
+      tile_c = tile;
+      __syncthreads();
+    }
+    if (pass == 0) {
+      const int64_t ob = ((int64_t)pc.b * (ND * g.K) + ND * tap) * g.S_o + pc.pix;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) delta_n[a] = offset[ob + (int64_t)a * g.S_o];
+      if (MOD) m_n = mask[((int64_t)pc.b * g.K + tap) * g.S_o + pc.pix];
+    }
+    const int cbase_p = (passp * WAVES_C + wc) * 64;   // channels of the parked accumulators
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+#pragma unroll
+    for (int q = 0; q < NBATCH; ++q) {
+      float2 v[RB][NP];
+      gather(q, cbase_p, v);
+      asm volatile("" ::: "memory");   // IR-level fence: keep batch q's gathers here
+      __builtin_amdgcn_sched_barrier(0);
+      if (QPQ > 0) {
+#pragma unroll
+        for (int jq = 0; jq < QPQ; ++jq) quad(tap, pass, (q * QPQ + jq) * 4);
+      } else {
+        for (int qd = nquads * q / NBATCH; qd < nquads * (q + 1) / NBATCH; ++qd) quad(tap, pass, qd * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      consume(q, cbase_p, v);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the parked tap is complete after its last pass; its group is flushed at a group / tile end
+    if (it > 0 && passp == passes - 1) finish_tap(tapp, false);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) accp[i] = acc[i];
+    pp = pc;
+    tapp = tap;
+    passp = pass;
+    if (++pass == passes) {
+      pass = 0;
+      if (++tap == g.K) { tap = 0; ++tile; }
+    }
+  }
+  // ---- drain of the last iteration ----
+  {
+    if (passp == 0) new_tap_state(tapp);
+    const int cbase_p = (passp * WAVES_C + wc) * 64;
+#pragma unroll
+    for (int q = 0; q < NBATCH; ++q) {
+      float2 v[RB][NP];
+      gather(q, cbase_p, v);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      consume(q, cbase_p, v);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    finish_tap(tapp, true);
   }
 }
 
@@ -524,6 +605,19 @@ int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq
   return check_launch("pack_wq");
 }
 
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
+}
+
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
   const int bnp = 32 * (4 / bd.waves_c);
   return ((size_t)bnp * (bd.ochunks * 16 + 4) + (size_t)kTapGroup * 128 * (g.nd + 1)) * sizeof(float);
@@ -531,26 +625,38 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, hipStream_t stream) {
-#define LAUNCH_BD(ND, MOD, WC)                                                                  \
+#define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
   do {                                                                                          \
     const int bnp = 32 * (4 / WC);                                                              \
     const int ntiles = (g.N + bnp - 1) / bnp;                                                   \
     const size_t lds = bwd_data_lds_bytes(g, bd);                                               \
     if (lds > 64 * 1024) {                                                                      \
-      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC>,      \
+      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ>, \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; } \
     }                                                                                           \
-    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC>), dim3(ntiles), dim3(256), lds, stream, \
+    /* complete dispatch rounds of one-tile workgroups (2 per CU by registers, fewer by LDS),  */ \
+    /* then the units of the leftover tiles spread over one more, shorter, round              */ \
+    const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;                                           \
+    const int slots = num_cus() * per_cu;                                                       \
+    const int n_full = ntiles / slots * slots;                                                  \
+    const int n_tail = (int)std::min<int64_t>((int64_t)(ntiles - n_full) * g.K, slots);         \
+    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ>), dim3(n_full + n_tail),        \
+                       dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
-                       (float *)t.grad_offset, (float *)t.grad_mask, ntiles);                   \
+                       (float *)t.grad_offset, (float *)t.grad_mask, ntiles, n_full, n_tail);   \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \
-    if (bd.waves_c == 4) LAUNCH_BD(ND, MOD, 4);                                                 \
-    else if (bd.waves_c == 2) LAUNCH_BD(ND, MOD, 2);                                            \
-    else LAUNCH_BD(ND, MOD, 1);                                                                 \
+    const int nbatch = ND == 2 ? 4 : 8, nquads = bd.ochunks / 4;                                \
+    const int qpq = (nquads % nbatch == 0 && nquads / nbatch <= 2) ? nquads / nbatch : 0;       \
+    if (bd.waves_c == 4) {                                                                      \
+      if (qpq == 1) LAUNCH_BD(ND, MOD, 4, 1);                                                   \
+      else if (qpq == 2) LAUNCH_BD(ND, MOD, 4, 2);                                              \
+      else LAUNCH_BD(ND, MOD, 4, 0);                                                            \
+    } else if (bd.waves_c == 2) LAUNCH_BD(ND, MOD, 2, 0);                                       \
+    else LAUNCH_BD(ND, MOD, 1, 0);                                                              \
   } while (0)
   if (g.nd == 2) { if (g.modulated) LAUNCH_BD2(2, true); else LAUNCH_BD2(2, false); }
   else { if (g.modulated) LAUNCH_BD2(3, true); else LAUNCH_BD2(3, false); }

@@ -84,7 +84,7 @@ BwdDims bwd_dims(const Geom &g) {
   if (splits < 1) splits = 1;
   bd.pairs_per_split = (pairs + splits - 1) / splits;
   bd.splits = (pairs + bd.pairs_per_split - 1) / bd.pairs_per_split;
-  bd.ochunks = (g.O + 31) / 32 * 2;
+  bd.ochunks = (g.O + 63) / 64 * 4;   // K loop of GEMM-1 is unrolled 4x
   bd.waves_c = g.C > 128 ? 4 : (g.C > 64 ? 2 : 1);
   if (const char *e = getenv("MDCONV_BD_WAVES_C")) bd.waves_c = atoi(e);   // experiments
   bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
