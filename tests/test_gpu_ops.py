@@ -1,0 +1,77 @@
+"""torch.library ops on the GPU: same numbers as the legacy autograd.Functions (and therefore as
+the oracle, tests/test_gpu_parity.py), opcheck's schema / fake-tensor / autograd-registration
+checks, and tracing through torch.compile without graph breaks."""
+import pytest
+import torch
+
+from tests import cases
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["mdcn2d_s2_g4_dg2", "dcn2d_dil2_dg4", "dcn3d_s2_g2", "mdcn3d_dil2_dg2",
+         "mfma_mdcn2d_c32_o48_9x10"]
+
+
+def _args(case, dev="cuda"):
+    t = cases.make_inputs(case, device=dev)
+    nd = cases.ndim(case)
+    tup = lambda v: [v] * nd if isinstance(v, int) else list(v)
+    return t, dict(stride=tup(case["stride"]), padding=tup(case["padding"]), dilation=tup(case["dilation"]),
+                   groups=case["groups"], deformable_groups=case["dgroups"], in_step=case["in_step"])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_op_matches_legacy_function(name):
+    import modulated_deform_conv_amd.modulated_deform_conv as pkg
+    import modulated_deform_conv_amd.ops as ops
+    case = cases.CASE_BY_NAME[name]
+    t, conf = _args(case)
+    nd, modulated = cases.ndim(case), t["mask"] is not None
+    leaves = {n: t[n].clone().requires_grad_(True) for n in ("input", "offset", "mask", "weight", "bias")
+              if t[n] is not None}
+    out = ops.deform_conv(leaves["input"], leaves["offset"], leaves.get("mask"), leaves["weight"],
+                          leaves.get("bias"), **conf)
+    out.backward(t["grad_output"])
+    fn = getattr(pkg, "%sdeform_conv%dd" % ("modulated_" if modulated else "", nd))
+    ref = {n: t[n].clone().requires_grad_(True) for n in leaves}
+    head = (ref["input"], ref["offset"]) + ((ref["mask"],) if modulated else ())
+    out_ref = fn(*head, ref["weight"], ref.get("bias"), conf["stride"], conf["padding"],
+                 conf["dilation"], conf["groups"], conf["deformable_groups"], conf["in_step"])
+    out_ref.backward(t["grad_output"])
+    assert_close("output", out, out_ref, 1e-6)
+    for n in leaves:
+        assert_close("grad_" + n, leaves[n].grad, ref[n].grad, 1e-6)
+
+
+@pytest.mark.parametrize("name", ["mdcn2d_basic", "dcn3d_basic"])
+def test_opcheck(name):
+    import modulated_deform_conv_amd.ops as ops
+    case = cases.CASE_BY_NAME[name]
+    t, conf = _args(case)
+    args = (t["input"].requires_grad_(True), t["offset"].requires_grad_(True),
+            None if t["mask"] is None else t["mask"].requires_grad_(True),
+            t["weight"].requires_grad_(True), None if t["bias"] is None else t["bias"].requires_grad_(True))
+    torch.library.opcheck(ops.deform_conv, args, conf,
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration",
+                                      "test_aot_dispatch_static"))
+
+
+def test_torch_compile_traces_without_graph_break():
+    import modulated_deform_conv_amd.ops as ops
+    case = cases.CASE_BY_NAME["mdcn2d_basic"]
+    t, conf = _args(case)
+
+    def step(x, off, m, w, b):
+        y = ops.deform_conv(x, off, torch.sigmoid(m), w, b, **conf)
+        return torch.relu(y).sum()
+
+    leaves = [t[n].clone().requires_grad_(True) for n in ("input", "offset", "mask", "weight", "bias")]
+    eager = step(*leaves)
+    g_eager = torch.autograd.grad(eager, leaves)
+    compiled = torch.compile(step, backend="aot_eager", fullgraph=True)
+    out = compiled(*leaves)
+    g = torch.autograd.grad(out, leaves)
+    assert_close("loss", out.reshape(1), eager.reshape(1), 1e-6)
+    for a, b_, n in zip(g, g_eager, ("input", "offset", "mask", "weight", "bias")):
+        assert_close("grad_" + n, a, b_, 1e-6)
