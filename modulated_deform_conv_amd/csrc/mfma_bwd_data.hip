@@ -665,8 +665,8 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
   return check_launch("mfma_bwd_data");
 }
 
-int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol, int *cnt,
-               int *rowptr, void *entries, hipStream_t stream) {
+int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
+                  hipStream_t stream) {
   const int64_t samples = (int64_t)g.B * g.K * g.S_o;
   const size_t cnt_bytes = (size_t)g.B * g.S_i * sizeof(int);
   hipError_t e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
@@ -688,9 +688,13 @@ int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *
   e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
   if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
   LAUNCH_CSR2(true);
-  if ((rc = check_launch("csr_fill"))) return rc;
+  return check_launch("csr_fill");
 #undef LAUNCH_CSR2
 #undef LAUNCH_CSR
+}
+
+int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *rowptr,
+               const void *entries, hipStream_t stream) {
   const int qtiles = (g.S_i + 31) / 32;
   const dim3 grid(g.B * qtiles, 1);
   if (g.nd == 2)
@@ -699,7 +703,6 @@ int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *
   else
     hipLaunchKernelGGL((col2im_gather_kernel<3>), grid, dim3(256), 0, stream, g, gcol, rowptr,
                        (const int2 *)entries, (float *)t.grad_input);
-  (void)bd;
   return check_launch("col2im_gather");
 }
 

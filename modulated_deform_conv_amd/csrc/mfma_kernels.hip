@@ -4,6 +4,7 @@
 
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 namespace mdconv {
@@ -221,7 +222,46 @@ int zero(void *p, size_t bytes, hipStream_t s) {
   return MDCONV_OK;
 }
 
-// fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`)
+// A second stream per device for the fork/join inside the backward.
+struct Side {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, csr = nullptr, gemm1 = nullptr, join = nullptr;
+  bool ok = false;
+  std::mutex enqueue;   // one backward at a time records / waits on the three events
+};
+Side *side_for_current_device() {
+  static Side sides[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Side &sd = sides[dev];
+  if (!sd.stream) {
+    // opt-in: at cfg2 the fork/join LOSES (4.34 vs 4.16 ms per step) -- see backward_chunk_f32
+    const char *e = getenv("MDCONV_SIDE_STREAM");
+    if (!e || atoi(e) == 0) return nullptr;
+    if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&sd.csr, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&sd.gemm1, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess)
+      sd.ok = true;
+  }
+  return sd.ok ? &sd : nullptr;
+}
+
+// fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`).
+// Two chains, forked onto a side stream and joined before returning:
+//   caller's stream : pack_wq -> GEMM-1 + coordinate gradients ----------> col2im gather
+//   side stream     : CSR build, tap table, pack grad_out -> [wait GEMM-1] -> GEMM-2, reduce, bias
+// so the small integer / packing kernels run under GEMM-1 and the HBM-bound col2im gather runs
+// under the MFMA-bound GEMM-2 instead of after it (disjoint workspace regions and gradients).
+// The two GEMMs themselves are kept apart: run concurrently they only halve each other
+// (measured 2.8 + 2.3 ms overlapped vs 1.2 + 1.2 ms back to back).
+// Measured at cfg2 this overlap does NOT pay either: GEMM-1 slows from 1.21 to 1.41 ms next to the
+// small kernels and GEMM-2 from 1.15 to 1.74 ms next to the gather (they compete for the same
+// L2 / texture path), 4.34 vs 4.16 ms per step.  It is therefore off unless MDCONV_SIDE_STREAM=1;
+// with it off both chains are issued in order on the caller's stream.
 int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t stream) {
   const BwdDims bd = bwd_dims(g);
   float *wq = (float *)(base + bd.off_wq);
@@ -229,20 +269,46 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   int *table = (int *)(base + bd.off_table);
   float *part = (float *)(base + bd.off_part);
   float *gcol = (float *)(base + bd.off_gcol);
+  int *cnt = (int *)(base + bd.off_cnt), *rowptr = (int *)(base + bd.off_rowptr);
+  void *entries = base + bd.off_entries;
+  Side *sd = side_for_current_device();
+  hipStream_t s2 = sd ? sd->stream : stream;
+  std::unique_lock<std::mutex> lock;
+  if (sd) lock = std::unique_lock<std::mutex>(sd->enqueue);
   int rc;
-  // grad_offset / grad_mask (+ grad_col), then grad_input through the inverted scatter map
+#define HIP_OK(x)                                                                     \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) { set_error(#x ": %s", hipGetErrorString(e_)); return MDCONV_ELAUNCH; } \
+  } while (0)
+  if (sd) {
+    HIP_OK(hipEventRecord(sd->fork, stream));
+    HIP_OK(hipStreamWaitEvent(s2, sd->fork, 0));
+  }
+  // side chain, part 1: everything that depends on offset / mask / grad_out only
+  if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, s2))) return rc;
+  if (sd) HIP_OK(hipEventRecord(sd->csr, s2));
+  if ((rc = build_tap_table_f32(g, bd, t, table, s2))) return rc;
+  if ((rc = pack_gout_f32(g, bd, (const float *)t.grad_output, ga, s2))) return rc;
+  // main chain: grad_offset / grad_mask (+ grad_col)
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
   profile_mark(1, true, stream);
   rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, stream);
   profile_mark(1, false, stream);
   if (rc) return rc;
-  if ((rc = col2im_f32(g, bd, t, gcol, (int *)(base + bd.off_cnt), (int *)(base + bd.off_rowptr),
-                       base + bd.off_entries, stream)))
-    return rc;
-  // grad_weight / grad_bias
-  if ((rc = build_tap_table_f32(g, bd, t, table, stream))) return rc;
-  if ((rc = pack_gout_f32(g, bd, (const float *)t.grad_output, ga, stream))) return rc;
-  return mfma_bwd_weight_f32(g, bd, t, ga, table, part, stream);
+  // side chain, part 2: grad_weight / grad_bias, after GEMM-1
+  if (sd) {
+    HIP_OK(hipEventRecord(sd->gemm1, stream));
+    HIP_OK(hipStreamWaitEvent(s2, sd->gemm1, 0));
+  }
+  if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, s2))) return rc;
+  if (sd) HIP_OK(hipEventRecord(sd->join, s2));
+  // main chain: grad_input through the inverted scatter map
+  if (sd) HIP_OK(hipStreamWaitEvent(stream, sd->csr, 0));
+  if ((rc = col2im_f32(g, t, gcol, rowptr, entries, stream))) return rc;
+  if (sd) HIP_OK(hipStreamWaitEvent(stream, sd->join, 0));
+#undef HIP_OK
+  return 0;
 }
 
 }  // namespace
