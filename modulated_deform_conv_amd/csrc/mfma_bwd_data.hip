@@ -40,6 +40,8 @@ int grid_for(int64_t total) {
 
 // W[o][c][tap] -> wq[tap][ochunk][cblk][q][lane][s] = W[ochunk*16 + 8q + 4(lane>>5) + s]
 //                                                      [cblk*32 + (lane&31)][tap]   (0 padded)
+// With groups the weight is expanded to its dense block-diagonal form (0 where o and c belong to
+// different groups); GEMM-1 then only walks the o-chunks that can be non-zero for its channels.
 __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int cblks,
                                                       const float *__restrict__ w,
                                                       float *__restrict__ wq) {
@@ -57,7 +59,8 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int o = ob + s;
-      v[s] = (o < g.O && c < g.C) ? w[((int64_t)o * g.C + c) * g.K + tap] : 0.f;
+      v[s] = (o < g.O && c < g.C && o / g.Og == c / g.Cg)
+                 ? w[((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap] : 0.f;
     }
     reinterpret_cast<float4 *>(wq)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   const int T_o = bd.ochunks;              // multiple of 4
   const int gpitch = T_o * 16 + 4;         // floats per pixel row of the grad_out tile
   float *Gs = smem;                        // [BNP][gpitch]
-  float *red = smem + BNP * gpitch;        // [kTapGroup][WAVES_C][ND + 1][BNP]
+  float *red = smem + BNP * gpitch;        // [kTapGroup][nblk][ND + 1][BNP]
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
   // wave id as an SGPR: anything derived from threadIdx is 'divergent' to hipcc, and a divergent
@@ -136,6 +139,11 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   const int passes = bd.cblks_q / (2 * WAVES_C);
   const int iters = (u1 - u0) * passes;
   const int nquads = T_o / 4;
+  // Deformable groups: every 64-channel block (one wave, one pass) lies inside one group, has its
+  // own offsets / mask and its own partial grad_offset / grad_mask ("per block" mode); with one
+  // group the corner sums run on over the passes and only the WAVES_C waves are reduced.
+  const bool per_block = g.DG > 1;
+  const int nblk = per_block ? passes * WAVES_C : WAVES_C;
   const int frag_bytes = 64 * 16;                      // one [lane][4] fragment
   const int chunk_bytes = bd.cblks_q * 2 * frag_bytes; // one ochunk of wq
   const rsrc_t r_in = make_rsrc(input, (size_t)g.B * g.C * g.S_i * 4);
@@ -144,14 +152,22 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   const int a_lane = lane * 16;
   const float *Bb = Gs + (wp * 32 + (lane & 31)) * gpitch + 4 * kh;
 
-  // byte offset of A chunk t of (tap, pass); t >= T_o runs on into the following (tap, pass)
-  auto a_off = [&](int tap, int pass, int t) {
-    if (t >= T_o) {
-      t -= T_o;
-      if (++pass == passes) { pass = 0; tap = tap + 1 == g.K ? 0 : tap + 1; }
-    }
-    return (tap * T_o + t) * chunk_bytes + ((pass * WAVES_C + wc) * 2) * 2 * frag_bytes;
+  // K range of a pass: with conv groups only the o-chunks of the groups that own this wave's 64
+  // channels carry non-zero weights (quads of 4 chunks = 64 output channels)
+  auto krange = [&](int pass, int &q_lo, int &q_n) {
+    if (g.G == 1) { q_lo = 0; q_n = nquads; return; }
+    const int cb = (pass * WAVES_C + wc) * 64;
+    const int c_lo = min(cb, g.C - 1), c_hi = min(cb + 63, g.C - 1);
+    const int o_lo = (c_lo / g.Cg) * g.Og, o_hi = (c_hi / g.Cg + 1) * g.Og;
+    q_lo = o_lo / 64;
+    q_n = (o_hi + 63) / 64 - q_lo;
   };
+  auto a_base = [&](int tap, int pass, int q_lo) {
+    return (tap * T_o + q_lo * 4) * chunk_bytes + ((pass * WAVES_C + wc) * 2) * 2 * frag_bytes;
+  };
+  // A stream of the running iteration (a_cur, n_cur chunks) and of the following one (a_nxt)
+  int a_cur = 0, n_cur = 0, a_nxt = 0, b_cur = 0;
+  auto a_off = [&](int t) { return t < n_cur ? a_cur + t * chunk_bytes : a_nxt + (t - n_cur) * chunk_bytes; };
   auto load_a = [&](float4 (&ra)[MB][2], int soff) {
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -161,10 +177,13 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   };
   float4 ra0[MB][2], ra1[MB][2], ra2[MB][2], ra3[MB][2];
   {
-    const int tap_first = u0 % g.K;
-    load_a(ra0, a_off(tap_first, 0, 0));
-    load_a(ra1, a_off(tap_first, 0, 1));
-    load_a(ra2, a_off(tap_first, 0, 2));
+    int q_lo, q_n;
+    krange(0, q_lo, q_n);
+    a_cur = a_base(u0 % g.K, 0, q_lo);
+    n_cur = 4;   // the first three chunks of the first iteration
+    load_a(ra0, a_off(0));
+    load_a(ra1, a_off(1));
+    load_a(ra2, a_off(2));
   }
 
   // ---- the pixel this lane owns in the accumulator layout: of the tile whose K loop runs
@@ -296,7 +315,8 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   // ---- tap `tapp` of the parked tile is complete for this wave's channels: reduce, park in
   // LDS; `flush` (end of a tap group / of the tile / of the unit range) writes the group out ----
   int grp_lo = (u0 % g.K) % kTapGroup;   // first slot of the current tap group held in `red`
-  auto finish_tap = [&](int tapp, bool last) {
+  const int bpd = per_block ? g.Cdg / 64 : nblk;   // 64-channel blocks per deformable group
+  auto finish_tap = [&](int tapp, int blk, bool flush_ok, bool last) {
     float goff[ND], gm = 0.f;
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) gm = fmaf(w[ci], S[ci], gm);
@@ -307,32 +327,35 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       for (int ci = 0; ci < NC; ++ci) goff[a] = fmaf(dw[a][ci], S[ci], goff[a]);
       goff[a] *= mg;
     }
-    // reduce over channels: the two half-waves here, the WAVES_C channel-waves at the flush
+    // reduce over channels: the two half-waves here, the blocks of a group at the flush
 #pragma unroll
     for (int a = 0; a < ND; ++a) goff[a] += __shfl_xor(goff[a], 32, 64);
     gm += __shfl_xor(gm, 32, 64);
     const int slot = tapp % kTapGroup;
     if (kh == 0) {
-      float *rp = red + ((slot * WAVES_C + wc) * (ND + 1)) * BNP + wp * 32 + lane;
+      float *rp = red + ((slot * nblk + blk) * (ND + 1)) * BNP + wp * 32 + lane;
 #pragma unroll
       for (int a = 0; a < ND; ++a) rp[a * BNP] = goff[a];
       rp[ND * BNP] = gm;
     }
-    if (slot == kTapGroup - 1 || tapp == g.K - 1 || last) {
+    if (flush_ok && (slot == kTapGroup - 1 || tapp == g.K - 1 || last)) {
       __syncthreads();
-      // single owner of every (b, tap, pix): plain accumulate (the C ABI accumulates into grads)
+      // single owner of every (b, dg, tap, pix): plain accumulate (the C ABI accumulates into grads)
       const int tap0 = tapp - slot;
-      const int items = (slot + 1 - grp_lo) * (ND + 1) * BNP;
+      const int per_slot = g.DG * (ND + 1) * BNP;
+      const int items = (slot + 1 - grp_lo) * per_slot;
       for (int x = tid; x < items; x += 256) {
-        const int jj = x % BNP, a = (x / BNP) % (ND + 1), sl = grp_lo + x / (BNP * (ND + 1));
+        const int jj = x % BNP, a = (x / BNP) % (ND + 1), dgi = (x / (BNP * (ND + 1))) % g.DG;
+        const int sl = grp_lo + x / per_slot;
         const int n = pp.n0 + jj;
         if (n < g.N && (MOD || a < ND)) {
           float sum = 0.f;
-#pragma unroll
-          for (int y = 0; y < WAVES_C; ++y) sum += red[((sl * WAVES_C + y) * (ND + 1) + a) * BNP + jj];
+          for (int y = 0; y < bpd; ++y)
+            sum += red[((sl * nblk + dgi * bpd + y) * (ND + 1) + a) * BNP + jj];
           const int b = n / g.S_o, pix = n - b * g.S_o, tp = tap0 + sl;
-          if (a < ND) grad_offset[((int64_t)b * (ND * g.K) + ND * tp + a) * g.S_o + pix] += sum;
-          else grad_mask[((int64_t)b * g.K + tp) * g.S_o + pix] += sum;
+          const int64_t seg = (int64_t)b * g.DG + dgi;
+          if (a < ND) grad_offset[(seg * (ND * g.K) + ND * tp + a) * g.S_o + pix] += sum;
+          else grad_mask[(seg * g.K + tp) * g.S_o + pix] += sum;
         }
       }
       __syncthreads();
@@ -358,26 +381,27 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   };
   // four chunks t .. t+3 of (tap, pass); A runs three chunks ahead (into the next iteration).
   // (Fetching the B fragments a chunk ahead as well was measured slower: 1.24 -> 1.30 ms.)
-  auto quad = [&](int tap, int pass, int t) {
-    load_a(ra3, a_off(tap, pass, t + 3));
+  auto quad = [&](int t) {
+    const float *bq = Bb + b_cur;
+    load_a(ra3, a_off(t + 3));
     __builtin_amdgcn_sched_barrier(0);
-    mma(ra0, Bb + t * 16);
-    load_a(ra0, a_off(tap, pass, t + 4));
+    mma(ra0, bq + t * 16);
+    load_a(ra0, a_off(t + 4));
     __builtin_amdgcn_sched_barrier(0);
-    mma(ra1, Bb + (t + 1) * 16);
-    load_a(ra1, a_off(tap, pass, t + 5));
+    mma(ra1, bq + (t + 1) * 16);
+    load_a(ra1, a_off(t + 5));
     __builtin_amdgcn_sched_barrier(0);
-    mma(ra2, Bb + (t + 2) * 16);
-    load_a(ra2, a_off(tap, pass, t + 6));
+    mma(ra2, bq + (t + 2) * 16);
+    load_a(ra2, a_off(t + 6));
     __builtin_amdgcn_sched_barrier(0);
-    mma(ra3, Bb + (t + 3) * 16);
+    mma(ra3, bq + (t + 3) * 16);
   };
 
   int tile_c = -1;   // tile whose grad_out is in LDS
   int tapp = 0, passp = 0;   // (tap, pass) of the parked accumulators
   int tile = u0 / g.K, tap = u0 - tile * g.K, pass = 0;   // of the running K loop
   for (int it = 0; it < iters; ++it) {
-    if (it > 0 && passp == 0) new_tap_state(tapp);
+    if (it > 0 && (passp == 0 || per_block)) new_tap_state(tapp);
     if (tile != tile_c) {
       if (tile_c >= 0) __syncthreads();   // every wave is done with the previous tile's K loops
       load_gout_tile(tile);
@@ -385,11 +409,26 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       tile_c = tile;
       __syncthreads();
     }
-    if (pass == 0) {
-      const int64_t ob = ((int64_t)pc.b * (ND * g.K) + ND * tap) * g.S_o + pc.pix;
+    if (pass == 0 || per_block) {
+      const int dg = per_block ? min((pass * WAVES_C + wc) * 64, g.C - 1) / g.Cdg : 0;
+      const int64_t seg = (int64_t)pc.b * g.DG + dg;
+      const int64_t ob = (seg * (ND * g.K) + ND * tap) * g.S_o + pc.pix;
 #pragma unroll
       for (int a = 0; a < ND; ++a) delta_n[a] = offset[ob + (int64_t)a * g.S_o];
-      if (MOD) m_n = mask[((int64_t)pc.b * g.K + tap) * g.S_o + pc.pix];
+      if (MOD) m_n = mask[(seg * g.K + tap) * g.S_o + pc.pix];
+    }
+    // A / B streams of this iteration and the start of the next one (for the prefetch overrun)
+    int nq;
+    {
+      int q_lo, tn = tap, pn = pass + 1;
+      krange(pass, q_lo, nq);
+      a_cur = a_base(tap, pass, q_lo);
+      n_cur = nq * 4;
+      b_cur = q_lo * 64;
+      if (pn == passes) { pn = 0; tn = tap + 1 == g.K ? 0 : tap + 1; }
+      int q_lo2, nq2;
+      krange(pn, q_lo2, nq2);
+      a_nxt = a_base(tn, pn, q_lo2);
     }
     const int cbase_p = (passp * WAVES_C + wc) * 64;   // channels of the parked accumulators
 #pragma unroll
@@ -405,17 +444,19 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       __builtin_amdgcn_sched_barrier(0);
       if (QPQ > 0) {
 #pragma unroll
-        for (int jq = 0; jq < QPQ; ++jq) quad(tap, pass, (q * QPQ + jq) * 4);
+        for (int jq = 0; jq < QPQ; ++jq) quad((q * QPQ + jq) * 4);
       } else {
-        for (int qd = nquads * q / NBATCH; qd < nquads * (q + 1) / NBATCH; ++qd) quad(tap, pass, qd * 4);
+        for (int qd = nq * q / NBATCH; qd < nq * (q + 1) / NBATCH; ++qd) quad(qd * 4);
       }
       __builtin_amdgcn_sched_barrier(0);
       consume(q, cbase_p, v);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the parked tap is complete after its last pass; its group is flushed at a group / tile end
-    if (it > 0 && passp == passes - 1) finish_tap(tapp, false);
+    // the parked tap is complete after its last pass (per block: after every pass); its group is
+    // flushed at a group / tile end
+    if (it > 0 && (passp == passes - 1 || per_block))
+      finish_tap(tapp, per_block ? passp * WAVES_C + wc : wc, passp == passes - 1, false);
 #pragma unroll
     for (int i = 0; i < MB; ++i) accp[i] = acc[i];
     pp = pc;
@@ -428,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   }
   // ---- drain of the last iteration ----
   {
-    if (passp == 0) new_tap_state(tapp);
+    if (passp == 0 || per_block) new_tap_state(tapp);
     const int cbase_p = (passp * WAVES_C + wc) * 64;
 #pragma unroll
     for (int q = 0; q < NBATCH; ++q) {
@@ -440,12 +481,12 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
-    finish_tap(tapp, true);
+    finish_tap(tapp, per_block ? passp * WAVES_C + wc : wc, true, true);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// 2. inverse scatter map (CSR keyed by (b, tap, q)); DG == 1
+// 2. inverse scatter map (CSR keyed by (image, deformable group, input pixel))
 // ---------------------------------------------------------------------------------------------
 template <int ND, bool MOD, bool FILL>
 __global__ __launch_bounds__(256) void csr_pass_kernel(Geom g, const float *__restrict__ offset,
@@ -454,11 +495,12 @@ __global__ __launch_bounds__(256) void csr_pass_kernel(Geom g, const float *__re
                                                        const int *__restrict__ rowptr,
                                                        int2 *__restrict__ entries) {
   constexpr int NC = 1 << ND;
-  const int64_t total = (int64_t)g.B * g.K * g.S_o;
+  // a segment is one (image, deformable group): offset / mask are laid out [b][dg][...]
+  const int64_t total = (int64_t)g.B * g.DG * g.K * g.S_o;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int pix = (int)(i % g.S_o);
     const int tap = (int)((i / g.S_o) % g.K);
-    const int b = (int)(i / g.S_o / g.K);
+    const int b = (int)(i / g.S_o / g.K);   // segment index b * DG + dg
     int oc[ND], tcd[ND];
     out_coords<ND>(g, pix, oc);
     tap_coords<ND>(g, tap, tcd);
@@ -541,9 +583,10 @@ __global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * g.C, (size_t)g.K * g.S_o * g.C * 4);
-  const int *rp = rowptr + (int64_t)b * (g.S_i + 1);
-  const int2 *ent = entries + (int64_t)b * ((int64_t)g.K * g.S_o * NC);
   for (int cb = blockIdx.y * 256; cb < g.C; cb += gridDim.y * 256) {
+    const int seg = b * g.DG + cb / g.Cdg;   // C_dg is a multiple of 256 here (or DG == 1)
+    const int *rp = rowptr + (int64_t)seg * (g.S_i + 1);
+    const int2 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o * NC);
     const int c4 = cb + lane * 4;
     const int c_voff = (c4 < g.C ? c4 : 0) * 4;   // C % 4 == 0
     for (int qi = wave; qi < QT; qi += 4) {
@@ -596,6 +639,82 @@ __global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float 
   }
 }
 
+
+// Deformable groups narrower than 256 channels: LPD = C_dg / 4 lanes cover one group, so a wave
+// walks 64 / LPD input pixels of ONE group at a time (lane = (pixel j, channel quad r)); each lane
+// group follows its own list.  List entries are fetched LPD at a time (lane r <- entry r) and
+// broadcast inside the lane group with a width-limited shuffle.
+template <int ND, int LPD>
+__global__ __launch_bounds__(256) void col2im_gather_grouped_kernel(
+    Geom g, const float *__restrict__ gcol, const int *__restrict__ rowptr,
+    const int2 *__restrict__ entries, float *__restrict__ grad_input) {
+  constexpr int NC = 1 << ND;
+  constexpr int QT = 32, NQ = 64 / LPD;   // q per tile, q per wave step
+  constexpr int CDG = LPD * 4;             // channels per deformable group
+  constexpr int DPB = 256 / CDG;           // groups per 256-channel block
+  __shared__ float tile[256 * (QT + 1)];   // [c][q], pitch 33
+  const int qtiles = (g.S_i + QT - 1) / QT;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = bid / qtiles;
+  const int q0 = (bid - b * qtiles) * QT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane / LPD, r = lane % LPD;
+  const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * g.C, (size_t)g.K * g.S_o * g.C * 4);
+  for (int cb = 0; cb < g.C; cb += 256) {
+    // work items of the block: (group d of DPB) x (q step of QT / NQ)
+    for (int item = wave; item < DPB * (QT / NQ); item += 4) {
+      const int d = item / (QT / NQ), qi = (item % (QT / NQ)) * NQ + j;
+      const int c4 = cb + d * CDG + r * 4;
+      const int q = q0 + qi;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool on = q < g.S_i && c4 < g.C;
+      const int seg = b * g.DG + min(c4, g.C - 1) / g.Cdg;
+      const int *rp = rowptr + (int64_t)seg * (g.S_i + 1);
+      const int2 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o * NC);
+      const int e0 = on ? rp[q] : 0, e1 = on ? rp[q + 1] : 0;
+      const int c_voff = (c4 < g.C ? c4 : 0) * 4;
+      for (int base = e0; __any(base < e1); base += LPD) {
+        const int cnt = max(0, min(LPD, e1 - base));
+        const int2 mine = (r < cnt) ? ent[base + r] : make_int2(0, 0);   // weight 0, row 0 beyond
+        constexpr int UB = LPD < 16 ? LPD : 16;   // row loads in flight per step
+#pragma unroll
+        for (int u0 = 0; u0 < LPD; u0 += UB) {
+          float4 v[UB];
+          float we[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int src = __shfl(mine.x, u0 + u, LPD);
+            we[u] = __int_as_float(__shfl(mine.y, u0 + u, LPD));
+            v[u] = buf_load4(r_gc, src * g.C * 4 + c_voff, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            acc.x = fmaf(we[u], v[u].x, acc.x); acc.y = fmaf(we[u], v[u].y, acc.y);
+            acc.z = fmaf(we[u], v[u].z, acc.z); acc.w = fmaf(we[u], v[u].w, acc.w);
+          }
+        }
+      }
+      float *tp = tile + (d * CDG + r * 4) * (QT + 1) + qi;
+      tp[0] = acc.x; tp[QT + 1] = acc.y; tp[2 * (QT + 1)] = acc.z; tp[3 * (QT + 1)] = acc.w;
+    }
+    __syncthreads();
+    {
+      const int cl = threadIdx.x >> 2, qs = (threadIdx.x & 3) * 8;
+      for (int cc = cl; cc < 256; cc += 64) {
+        const int c = cb + cc;
+        if (c < g.C) {
+          float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q0 + qs;
+          const float *src = tile + cc * (QT + 1) + qs;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (q0 + qs + k < g.S_i) dst[k] += src[k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream) {
@@ -620,7 +739,9 @@ int num_cus() {
 
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
   const int bnp = 32 * (4 / bd.waves_c);
-  return ((size_t)bnp * (bd.ochunks * 16 + 4) + (size_t)kTapGroup * 128 * (g.nd + 1)) * sizeof(float);
+  const int passes = bd.cblks_q / (2 * bd.waves_c);
+  const size_t red = (size_t)kTapGroup * 128 * (g.DG > 1 ? passes : 1) * (g.nd + 1);
+  return ((size_t)bnp * (bd.ochunks * 16 + 4) + red) * sizeof(float);
 }
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
@@ -650,7 +771,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \
     const int nbatch = ND == 2 ? 4 : 8, nquads = bd.ochunks / 4;                                \
-    const int qpq = (nquads % nbatch == 0 && nquads / nbatch <= 2) ? nquads / nbatch : 0;       \
+    const int qpq = (g.G == 1 && nquads % nbatch == 0 && nquads / nbatch <= 2) ? nquads / nbatch : 0; \
     if (bd.waves_c == 4) {                                                                      \
       if (qpq == 1) LAUNCH_BD(ND, MOD, 4, 1);                                                   \
       else if (qpq == 2) LAUNCH_BD(ND, MOD, 4, 2);                                              \
@@ -667,8 +788,8 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
 
 int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
                   hipStream_t stream) {
-  const int64_t samples = (int64_t)g.B * g.K * g.S_o;
-  const size_t cnt_bytes = (size_t)g.B * g.S_i * sizeof(int);
+  const int64_t samples = (int64_t)g.B * g.DG * g.K * g.S_o;
+  const size_t cnt_bytes = (size_t)g.B * g.DG * g.S_i * sizeof(int);
   hipError_t e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
   if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
 #define LAUNCH_CSR(ND, MOD, FILL)                                                               \
@@ -683,7 +804,7 @@ int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *
   LAUNCH_CSR2(false);
   int rc = check_launch("csr_count");
   if (rc) return rc;
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B), dim3(256), 0, stream, g.S_i, cnt, rowptr);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B * g.DG), dim3(256), 0, stream, g.S_i, cnt, rowptr);
   if ((rc = check_launch("csr_scan"))) return rc;
   e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
   if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
@@ -697,12 +818,21 @@ int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *ro
                const void *entries, hipStream_t stream) {
   const int qtiles = (g.S_i + 31) / 32;
   const dim3 grid(g.B * qtiles, 1);
-  if (g.nd == 2)
+#define LAUNCH_GG(ND, LPD)                                                                      \
+  hipLaunchKernelGGL((col2im_gather_grouped_kernel<ND, LPD>), grid, dim3(256), 0, stream, g,    \
+                     gcol, rowptr, (const int2 *)entries, (float *)t.grad_input)
+  if (g.DG > 1 && g.Cdg == 64) {
+    if (g.nd == 2) LAUNCH_GG(2, 16); else LAUNCH_GG(3, 16);
+  } else if (g.DG > 1 && g.Cdg == 128) {
+    if (g.nd == 2) LAUNCH_GG(2, 32); else LAUNCH_GG(3, 32);
+  } else if (g.nd == 2) {
     hipLaunchKernelGGL((col2im_gather_kernel<2>), grid, dim3(256), 0, stream, g, gcol, rowptr,
                        (const int2 *)entries, (float *)t.grad_input);
-  else
+  } else {
     hipLaunchKernelGGL((col2im_gather_kernel<3>), grid, dim3(256), 0, stream, g, gcol, rowptr,
                        (const int2 *)entries, (float *)t.grad_input);
+  }
+#undef LAUNCH_GG
   return check_launch("col2im_gather");
 }
 

@@ -146,7 +146,14 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   const int a_voff = ((mtile * 8 + wave * MB) * 2 * 64 + lane) * 16;
   // rows of this wave beyond C_out are padding: skip their fragment loads and MFMAs (the wave
   // still gathers and synchronises) -- with C_out = 64 this is 4x less matrix work
-  const bool m_active = mtile * 256 + wave * 64 < g.O;
+  // ... and with conv groups only the output channels of the groups that own this tile's 32
+  // input channels can receive a gradient (the dense product is block diagonal)
+  bool m_active = mtile * 256 + wave * 64 < g.O;
+  if (g.G > 1) {
+    const int o_lo = (min(c0, g.C - 1) / g.Cg) * g.Og, o_hi = (min(c0 + 31, g.C - 1) / g.Cg + 1) * g.Og;
+    const int wo = mtile * 256 + wave * 64;
+    m_active = m_active && wo < o_hi && wo + 64 > o_lo;
+  }
   const int t_voff = kk * entry_bytes;
   const int chan_voff = (c0 + sub) * g.S_i * 4;   // this thread's first channel plane
   const int chan_soff = 16 * g.S_i * 4;           // its second channel is 16 planes further
@@ -261,19 +268,21 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
     }
 }
 
-// grad_weight[o][c][tap] += sum_split part[split][tap][o][c]
+// grad_weight[o][c_local][tap] += sum_split part[split][tap][o][c], c = group(o) * Cg + c_local
+// (only the block-diagonal entries of the dense product exist in the grouped weight)
 __global__ __launch_bounds__(256) void reduce_weight_kernel(Geom g, BwdDims bd,
                                                             const float *__restrict__ part,
                                                             float *__restrict__ grad_weight) {
-  const int64_t total = (int64_t)g.K * g.O * g.C;
+  const int64_t total = (int64_t)g.K * g.O * g.Cg;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % g.C);
-    const int o = (int)((i / g.C) % g.O);
-    const int tap = (int)(i / g.C / g.O);
+    const int cl = (int)(i % g.Cg);
+    const int o = (int)((i / g.Cg) % g.O);
+    const int tap = (int)(i / g.Cg / g.O);
+    const int c = (o / g.Og) * g.Cg + cl;
     float s = 0.f;
     for (int sp = 0; sp < bd.splits; ++sp)
       s += part[((size_t)(sp * g.K + tap) * bd.OgpB + o) * bd.Cp + c];
-    grad_weight[((int64_t)o * g.C + c) * g.K + tap] += s;
+    grad_weight[((int64_t)o * g.Cg + cl) * g.K + tap] += s;
   }
 }
 
@@ -337,7 +346,7 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
   profile_mark(2, false, stream);
   int rc = check_launch("mfma_bwd_weight");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_weight_kernel, dim3(grid_for((int64_t)g.K * g.O * g.C)), dim3(256), 0,
+  hipLaunchKernelGGL(reduce_weight_kernel, dim3(grid_for((int64_t)g.K * g.O * g.Cg)), dim3(256), 0,
                      stream, g, bd, part, (float *)t.grad_weight);
   if ((rc = check_launch("reduce_weight"))) return rc;
   if (g.with_bias) {

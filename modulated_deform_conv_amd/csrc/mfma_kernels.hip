@@ -96,9 +96,9 @@ BwdDims bwd_dims(const Geom &g) {
   bd.off_table = off; off += align_up((size_t)g.DG * g.K * bd.Np * 2 * (1 << g.nd) * sizeof(int));
   bd.off_part = off; off += align_up((size_t)bd.splits * g.K * bd.OgpB * bd.Cp * sizeof(float));
   bd.off_gcol = off; off += align_up((size_t)g.B * g.C * g.K * g.S_o * sizeof(float));
-  bd.off_cnt = off;  off += align_up((size_t)g.B * g.S_i * sizeof(int));
-  bd.off_rowptr = off; off += align_up((size_t)g.B * (g.S_i + 1) * sizeof(int));
-  bd.off_entries = off; off += align_up((size_t)g.B * g.K * g.S_o * nc * 8);
+  bd.off_cnt = off;  off += align_up((size_t)g.B * g.DG * g.S_i * sizeof(int));
+  bd.off_rowptr = off; off += align_up((size_t)g.B * g.DG * (g.S_i + 1) * sizeof(int));
+  bd.off_entries = off; off += align_up((size_t)g.B * g.DG * g.K * g.S_o * nc * 8);
   bd.off_end = off;
   return bd;
 }
@@ -315,10 +315,16 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
 
 bool mfma_supported(const Geom &g, int dtype, bool backward) {
   if (dtype != MDCONV_F32 && dtype != MDCONV_F16) return false;
-  if (g.Cg < 16 || g.Og < 16) return false;  // MFMA tiles would be mostly padding
   if (g.in_sz[g.nd - 1] < 2) return false;   // paired-corner gathers need 2 columns
-  if (!(g.DG == 1 || (g.Cdg % (2 * kBK) == 0 && g.Cg % (2 * kBK) == 0))) return false;
-  if (backward && (g.G != 1 || g.DG != 1 || g.C % 8)) return false;
+  if (!backward) {
+    if (g.Cg < 16 || g.Og < 16) return false;  // MFMA tiles would be mostly padding
+    if (!(g.DG == 1 || (g.Cdg % (2 * kBK) == 0 && g.Cg % (2 * kBK) == 0))) return false;
+  } else {
+    // conv groups run as a block-diagonal dense weight (GEMM-1 skips the empty o-chunks, GEMM-2
+    // the empty waves); deformable groups must be whole 64-channel blocks
+    if (g.C < 16 || g.O < 16 || g.C % 8) return false;
+    if (!(g.DG == 1 || g.Cdg == 64 || g.Cdg == 128 || g.Cdg % 256 == 0)) return false;
+  }
   if (backward && bwd_data_lds_bytes(g, bwd_dims(g)) > 150 * 1024) return false;   // grad_out tile lives in LDS
   Plan p;
   return make_plan(g, dtype, backward, &p);   // one image must fit 32-bit buffer offsets

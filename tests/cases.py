@@ -41,6 +41,14 @@ CASES = [
     # small but MFMA-eligible (>= 16 channels per group): the golden fixtures of the MFMA path
     _c("mfma_mdcn2d_c32_o48_9x10", M2, 2, 32, 48, (9, 10), 3, in_step=1, seed=17),
     _c("mfma_dcn3d_c16_o16_5x6x5", D3, 2, 16, 16, (5, 6, 5), 3, bias=False, seed=18),
+    # conv groups / deformable groups on the MFMA backward (block-diagonal dense weight, per-group
+    # coordinate gradients, CSR keyed by deformable group, grouped col2im gather)
+    _c("mfma_dcn2d_g2_c32_o32", D2, 2, 32, 32, (9, 8), 3, groups=2, in_step=1, seed=31),
+    _c("mfma_mdcn2d_g4_dg2_c128_o64", M2, 2, 128, 64, (12, 11), 3, groups=4, dgroups=2, tier="medium", seed=32),
+    _c("mfma_mdcn2d_g8_dg2_c256_o32", M2, 2, 256, 32, (7, 7), 3, groups=8, dgroups=2, tier="medium", seed=33),
+    _c("mfma_mdcn3d_g2_dg2_c128_o32", M3, 1, 128, 32, (5, 6, 5), 3, groups=2, dgroups=2, in_step=1, tier="medium", seed=34),
+    _c("cfg3s_mdcn2d_c256_g32_dg4_10x10", M2, 2, 256, 256, (10, 10), 3, groups=32, dgroups=4, bias=False, tier="medium", seed=35),
+    _c("mfma_dcn2d_dg4_c1024_o16", D2, 1, 1024, 16, (6, 6), 3, dgroups=4, bias=False, tier="medium", seed=36),
     # medium: down-scaled analogues of BASELINE.json configs[1..4] (same K / stride / dilation /
     # G : DG structure, channel counts that exercise the MFMA tiles incl. ragged edges)
     _c("cfg2s_mdcn2d_c64_28x28_b4", M2, 4, 64, 64, (28, 28), 3, tier="medium", seed=21),

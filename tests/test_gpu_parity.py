@@ -42,6 +42,20 @@ def test_fp32_auto_path(case):
     _check(case, torch.float32, "auto")
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"].startswith(("mfma_", "cfg2s_", "cfg3s_mdcn2d_c256",
+                                                                           "cfg4s_", "cfg5s_"))],
+                         ids=lambda c: c["name"])
+def test_backward_runs_on_the_mfma_path(case):
+    """Shapes meant for the matrix-core kernels must not silently fall back to the direct ones
+    (conv groups and deformable groups included)."""
+    assert _check(case, torch.float32, "auto")[1] == "mfma"
+
+
+def test_fp16_grouped_mfma_backward():
+    from tests.cases import CASE_BY_NAME
+    assert _check(CASE_BY_NAME["cfg3s_mdcn2d_c256_g32_dg4_10x10"], torch.float16, "auto")[1] == "mfma"
+
+
 @pytest.mark.parametrize("case", [c for c in CASES if c["tier"] == "small"], ids=lambda c: c["name"])
 def test_fp64(case):
     _check(case, torch.float64, "auto")
