@@ -23,7 +23,6 @@ namespace mdconv {
 
 namespace {
 
-constexpr int kPitch = 33;
 
 // ---------------------------------------------------------------------------------------------
 // tap table: per (dg, tap, n) the byte offsets of the 2^(ND-1) corner PAIRS (image base folded
@@ -107,14 +106,22 @@ __global__ __launch_bounds__(256) void pack_gout_kernel(Geom g, int Np, int mblk
 // ---------------------------------------------------------------------------------------------
 // the GEMM
 // ---------------------------------------------------------------------------------------------
-template <int ND, bool PADN>
+// Wave arrangement: WR x WC waves, MB 32-row tiles per wave -> workgroup tile
+// (WR * MB * 32 output channels) x (WC * 32 input channels):
+//   <4, 1, 2>  256 x 32   the default;
+//   <2, 2, 1>   64 x 64   C_out <= 64 (with the default, three of four waves would be padding).
+template <int ND, bool PADN, int WR, int WC, int MB>
 __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd,
                                                               const float *__restrict__ input,
                                                               const float *__restrict__ ga,
                                                               const int *__restrict__ table,
                                                               float *__restrict__ part) {
+  static_assert(WR * WC == 4, "four waves");
   constexpr int NC = 1 << ND, NP = NC / 2;
-  constexpr int BK = kBK, BN = 32, MB = 2;
+  constexpr int BK = kBK;
+  constexpr int RM = WR * MB * 32, CN = WC * 32;   // rows / channels per workgroup
+  constexpr int CT = CN / 16;                       // channels gathered per thread per chunk
+  constexpr int kPitch = CN + 1;
   __shared__ __attribute__((aligned(16))) float Bs[2 * BK * kPitch];
 
   // blockIdx.x = (mtile * K + tap) * cblks + cblk ; blockIdx.y = split
@@ -123,13 +130,14 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   const int tap = id % g.K;
   const int mtile = id / g.K;
   const int split = blockIdx.y;
-  const int c0 = cblk * 32;
+  const int c0 = cblk * CN;
   const int dg = min(c0, g.C - 1) / g.Cdg;
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
   // wave id as an SGPR: anything derived from threadIdx is 'divergent' to hipcc, and a divergent
   // buffer soffset is wrapped in a readfirstlane waterfall per load (cdna_hip_programming.md T20)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wcn = wave % WC;
   const int kk = tid & 15, sub = tid >> 4;   // pixel within the chunk, channel within the tile
 
   const int pairs_total = bd.Np / 32;
@@ -143,20 +151,21 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   const int entry_bytes = 2 * NC * 4;
   const rsrc_t r_tab = make_rsrc(table + (size_t)(dg * g.K + tap) * bd.Np * (2 * NC),
                                  (size_t)bd.Np * entry_bytes);
-  const int a_voff = ((mtile * 8 + wave * MB) * 2 * 64 + lane) * 16;
+  const int wo = mtile * RM + wr * MB * 32;   // first output channel of this wave
+  const int a_voff = ((wo / 32) * 2 * 64 + lane) * 16;
   // rows of this wave beyond C_out are padding: skip their fragment loads and MFMAs (the wave
-  // still gathers and synchronises) -- with C_out = 64 this is 4x less matrix work
-  // ... and with conv groups only the output channels of the groups that own this tile's 32
+  // still gathers and synchronises)
+  // ... and with conv groups only the output channels of the groups that own this wave's 32
   // input channels can receive a gradient (the dense product is block diagonal)
-  bool m_active = mtile * 256 + wave * 64 < g.O;
+  bool m_active = wo < g.O;
   if (g.G > 1) {
-    const int o_lo = (min(c0, g.C - 1) / g.Cg) * g.Og, o_hi = (min(c0 + 31, g.C - 1) / g.Cg + 1) * g.Og;
-    const int wo = mtile * 256 + wave * 64;
-    m_active = m_active && wo < o_hi && wo + 64 > o_lo;
+    const int cw = c0 + wcn * 32;
+    const int o_lo = (min(cw, g.C - 1) / g.Cg) * g.Og, o_hi = (min(cw + 31, g.C - 1) / g.Cg + 1) * g.Og;
+    m_active = m_active && wo < o_hi && wo + MB * 32 > o_lo;
   }
   const int t_voff = kk * entry_bytes;
-  const int chan_voff = (c0 + sub) * g.S_i * 4;   // this thread's first channel plane
-  const int chan_soff = 16 * g.S_i * 4;           // its second channel is 16 planes further
+  const int chan_voff = min(c0 + sub, g.C - 1) * g.S_i * 4;   // this thread's first channel plane
+  const int chan_soff = 16 * g.S_i * 4;                       // the others are 16 planes apart
 
   f32x16 acc[MB];
 #pragma unroll
@@ -183,18 +192,18 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
       }
     }
   };
-  float2 rg[2][NP];
+  float2 rg[CT][NP];
   auto gather = [&](const Tab &tb) {
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
       const int vo = tb.vo[pi] + chan_voff;
-      rg[0][pi] = buf_load2(r_in, vo, 0);
-      rg[1][pi] = buf_load2(r_in, vo, chan_soff);
+#pragma unroll
+      for (int i = 0; i < CT; ++i) rg[i][pi] = buf_load2(r_in, vo, i * chan_soff);
     }
   };
   auto commit = [&](const Tab &tb, int t, float *Bb) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < CT; ++i) {
       float val = tb.w[0] * rg[i][0].x;
       val = fmaf(tb.w[1], rg[i][0].y, val);
 #pragma unroll
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   };
   auto mma = [&](const float4 (&ra)[MB][2], const float *Bbuf) {
     if (!m_active) return;
-    const float *Bb = Bbuf + (lane & 31) + 4 * kh * kPitch;
+    const float *Bb = Bbuf + wcn * 32 + (lane & 31) + 4 * kh * kPitch;
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -258,12 +267,12 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   }
 
   // partial tile -> part[split][tap][o][c]   (lanes 0-31 = 32 consecutive channels)
-  float *dst = part + ((size_t)(split * g.K + tap) * bd.OgpB) * bd.Cp + c0 + (lane & 31);
+  float *dst = part + ((size_t)(split * g.K + tap) * bd.OgpB) * bd.Cp + c0 + wcn * 32 + (lane & 31);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int o = mtile * 256 + wave * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const int o = wo + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       dst[(size_t)o * bd.Cp] = acc[mb][r];
     }
 }
@@ -337,11 +346,16 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
   const bool padn = bd.Np != g.N;
   profile_mark(2, true, stream);
-#define LAUNCH_BW(ND, PADN)                                                                    \
-  hipLaunchKernelGGL((mfma_bwd_weight_kernel<ND, PADN>), grid, dim3(256), 0, stream, g, bd,      \
-                     (const float *)t.input, ga, table, part)
-  if (g.nd == 2) { if (padn) LAUNCH_BW(2, true); else LAUNCH_BW(2, false); }
-  else { if (padn) LAUNCH_BW(3, true); else LAUNCH_BW(3, false); }
+#define LAUNCH_BW(ND, PADN, WR, WC, MB)                                                         \
+  hipLaunchKernelGGL((mfma_bwd_weight_kernel<ND, PADN, WR, WC, MB>), grid, dim3(256), 0, stream, \
+                     g, bd, (const float *)t.input, ga, table, part)
+#define LAUNCH_BW2(ND, PADN)                                                                    \
+  do {                                                                                          \
+    if (bd.wtile == 1) LAUNCH_BW(ND, PADN, 2, 2, 1); else LAUNCH_BW(ND, PADN, 4, 1, 2);         \
+  } while (0)
+  if (g.nd == 2) { if (padn) LAUNCH_BW2(2, true); else LAUNCH_BW2(2, false); }
+  else { if (padn) LAUNCH_BW2(3, true); else LAUNCH_BW2(3, false); }
+#undef LAUNCH_BW2
 #undef LAUNCH_BW
   profile_mark(2, false, stream);
   int rc = check_launch("mfma_bwd_weight");

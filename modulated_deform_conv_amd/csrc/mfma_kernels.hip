@@ -73,11 +73,17 @@ int pack_weights_f32(const Geom &g, const PackDims &pd, const float *weight, flo
 BwdDims bwd_dims(const Geom &g) {
   BwdDims bd;
   bd.Np = (g.N + 31) / 32 * 32;
-  bd.OgpB = (g.O + 255) / 256 * 256;
+  // 64 x 64 tiles (all four waves busy when C_out <= 64) were measured SLOWER than 256 x 32 tiles
+  // with idle waves at cfg4 (GEMM-2 5.4 -> 8 ms): the kernel is bound by the cache-line traffic
+  // of the 8-corner gathers, not by the matrix work, so the variant stays an experiment.
+  bd.wtile = 0;
+  if (const char *e = getenv("MDCONV_BW_TILE")) bd.wtile = atoi(e) == 1 && g.O <= 64 ? 1 : 0;
+  const int rm = bd.wtile ? 64 : 256, cn = bd.wtile ? 64 : 32;
+  bd.OgpB = (g.O + rm - 1) / rm * rm;
   bd.mblks = bd.OgpB / 32;
-  bd.mtiles = bd.OgpB / 256;
-  bd.Cp = (g.C + 31) / 32 * 32;
-  bd.cblks = bd.Cp / 32;
+  bd.mtiles = bd.OgpB / rm;
+  bd.Cp = (g.C + cn - 1) / cn * cn;
+  bd.cblks = bd.Cp / cn;
   const int col_tiles = bd.mtiles * g.K * bd.cblks;
   const int pairs = bd.Np / 32;
   int splits = (1024 + col_tiles - 1) / col_tiles;       // ~4 workgroups per CU

@@ -71,8 +71,9 @@ __device__ __forceinline__ void buf_store4(rsrc_t r, int voff, int soff, float a
 // Dimensions / workspace layout of the MFMA backward (fp32, groups == 1).
 struct BwdDims {
   int Np;               // B*S_o rounded up to 32 (even number of 16-pixel chunks)
-  int OgpB, mblks, mtiles;   // C_out rounded up to 256; /32; /256
-  int Cp, cblks;        // C_in rounded up to 32; /32
+  int wtile;            // GEMM-2 workgroup tile: 0 = 256(o) x 32(c), 1 = 64 x 64 (C_out <= 64)
+  int OgpB, mblks, mtiles;   // C_out rounded up to the tile rows; /32; / tile rows
+  int Cp, cblks;        // C_in rounded up to the tile channels; / tile channels
   int splits, pairs_per_split;   // split-K of the grad_weight GEMM over pixel-chunk pairs
   int ochunks;          // C_out rounded up to 32, /16 (even): K chunks of GEMM-1
   int waves_c, cblks_q; // GEMM-1: waves along channels (4/2/1), 32-channel blocks of wq
