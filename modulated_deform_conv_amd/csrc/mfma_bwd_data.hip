@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
-    int ntiles, int n_full, int n_tail) {
+    float *__restrict__ ga, int ntiles, int n_full, int n_tail) {
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -216,6 +216,29 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     for (int o = osub; o < Opad; o += OSTEP) {
       const float v = src[(int64_t)min(o, g.O - 1) * g.S_o];
       dst[o] = (t_live && o < g.O) ? v : 0.f;
+    }
+  };
+
+  // The workgroup that runs tap 0 of a tile also emits the tile in the A-fragment order of GEMM-2
+  // (mfma_bwd_weight.hip): ga[nchunk][mblk][q][lane][s] = grad_out[o = mblk*32 + (lane&31)]
+  // [n = nchunk*16 + 8q + 4(lane>>5) + s], 0 outside -- the tile is in LDS anyway, so the separate
+  // packing pass over grad_out (0.08 ms at cfg2) is gone.
+  auto emit_ga = [&](int tile) {
+    constexpr int NCH = BNP / 16;
+    const int Opad = T_o * 16;
+    const int total = NCH * bd.mblks * 2 * 64;   // float4 units
+    for (int i = tid; i < total; i += 256) {
+      int r = i;
+      const int ln = r & 63; r >>= 6;
+      const int q = r & 1; r >>= 1;
+      const int mblk = r % bd.mblks, nch = r / bd.mblks;
+      const int nchunk = tile * NCH + nch;
+      if (nchunk * 16 >= bd.Np) continue;
+      const int o = mblk * 32 + (ln & 31);
+      const float *src = Gs + (nch * 16 + 8 * q + 4 * (ln >> 5)) * gpitch + o;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o < Opad) v = make_float4(src[0], src[gpitch], src[2 * gpitch], src[3 * gpitch]);
+      reinterpret_cast<float4 *>(ga)[((int64_t)nchunk * bd.mblks + mblk) * 128 + q * 64 + ln] = v;
     }
   };
 
@@ -408,6 +431,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       pix_of_tile(tile, pc);
       tile_c = tile;
       __syncthreads();
+      if (tap == 0 && pass == 0) emit_ga(tile);
     }
     if (pass == 0 || per_block) {
       const int dg = per_block ? min((pass * WAVES_C + wc) * 64, g.C - 1) / g.Cdg : 0;
@@ -745,7 +769,7 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
 }
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
-                      float *gcol, hipStream_t stream) {
+                      float *gcol, float *ga, hipStream_t stream) {
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
   do {                                                                                          \
     const int bnp = 32 * (4 / WC);                                                              \
@@ -766,7 +790,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
-                       (float *)t.grad_offset, (float *)t.grad_mask, ntiles, n_full, n_tail);   \
+                       (float *)t.grad_offset, (float *)t.grad_mask, ga, ntiles, n_full, n_tail); \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \

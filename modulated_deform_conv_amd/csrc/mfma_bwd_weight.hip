@@ -9,7 +9,7 @@
 //
 // Same VALU-starved structure as the forward kernel (see mfma_fwd.hip): both operands arrive by
 // raw buffer loads whose addresses live in SGPRs / lane constants:
-//   * A = grad_out, pre-packed once per call in MFMA-fragment order (`pack_gout`);
+//   * A = grad_out in MFMA-fragment order, emitted by GEMM-1 (mfma_bwd_data.hip, `emit_ga`);
 //   * B = col slab [16 pixels][32 channels]: a thread owns (pixel kk, channels sub, sub+16); the
 //     sampling state of (tap, pixel) changes every chunk, so it is NOT recomputed here (that
 //     would be ~60 VALU per chunk) but read from the per-call `tap table` (byte offsets + weights
@@ -69,37 +69,6 @@ __global__ __launch_bounds__(256) void tap_table_kernel(Geom g, int Np, const fl
       e[NC + 2 * pi] = __float_as_int(wx[pi]);
       e[NC + 2 * pi + 1] = __float_as_int(wy[pi]);
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// grad_out [B, O, S_o] -> A fragments: ga[nchunk][mblk][q][lane][s] =
-//   grad_out[o = mblk*32 + (lane&31)][n = nchunk*16 + 8q + 4(lane>>5) + s]   (0 outside)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_gout_kernel(Geom g, int Np, int mblks,
-                                                        const float *__restrict__ gout,
-                                                        float *__restrict__ ga) {
-  const int64_t total = (int64_t)(Np / 16) * mblks * 2 * 64;   // float4 units
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    int64_t r = i;
-    const int lane = (int)(r & 63); r >>= 6;
-    const int q = (int)(r & 1); r >>= 1;
-    const int mblk = (int)(r % mblks);
-    const int nchunk = (int)(r / mblks);
-    const int o = mblk * 32 + (lane & 31);
-    const int nb = nchunk * 16 + 8 * q + 4 * (lane >> 5);
-    float v[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int n = nb + s;
-      if (o < g.O && n < g.N) {
-        const int b = n / g.S_o, pix = n - b * g.S_o;
-        v[s] = gout[(int64_t)(b * g.O + o) * g.S_o + pix];
-      } else {
-        v[s] = 0.f;
-      }
-    }
-    reinterpret_cast<float4 *>(ga)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -331,14 +300,6 @@ int build_tap_table_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int 
   else { if (g.modulated) LAUNCH_TT(3, true); else LAUNCH_TT(3, false); }
 #undef LAUNCH_TT
   return check_launch("tap_table");
-}
-
-int pack_gout_f32(const Geom &g, const BwdDims &bd, const float *gout, float *ga,
-                  hipStream_t stream) {
-  const int64_t total = (int64_t)(bd.Np / 16) * bd.mblks * 2 * 64;
-  hipLaunchKernelGGL(pack_gout_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, bd.Np,
-                     bd.mblks, gout, ga);
-  return check_launch("pack_gout");
 }
 
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,

@@ -259,7 +259,7 @@ Side *side_for_current_device() {
 // fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`).
 // Two chains, forked onto a side stream and joined before returning:
 //   caller's stream : pack_wq -> GEMM-1 + coordinate gradients ----------> col2im gather
-//   side stream     : CSR build, tap table, pack grad_out -> [wait GEMM-1] -> GEMM-2, reduce, bias
+//   side stream     : CSR build, tap table -> [wait GEMM-1] -> GEMM-2, reduce, bias
 // so the small integer / packing kernels run under GEMM-1 and the HBM-bound col2im gather runs
 // under the MFMA-bound GEMM-2 instead of after it (disjoint workspace regions and gradients).
 // The two GEMMs themselves are kept apart: run concurrently they only halve each other
@@ -291,15 +291,14 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
     HIP_OK(hipEventRecord(sd->fork, stream));
     HIP_OK(hipStreamWaitEvent(s2, sd->fork, 0));
   }
-  // side chain, part 1: everything that depends on offset / mask / grad_out only
+  // side chain, part 1: everything that depends on offset / mask only
   if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, s2))) return rc;
   if (sd) HIP_OK(hipEventRecord(sd->csr, s2));
   if ((rc = build_tap_table_f32(g, bd, t, table, s2))) return rc;
-  if ((rc = pack_gout_f32(g, bd, (const float *)t.grad_output, ga, s2))) return rc;
   // main chain: grad_offset / grad_mask (+ grad_col)
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
   profile_mark(1, true, stream);
-  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, stream);
+  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, stream);   // also packs grad_out for GEMM-2
   profile_mark(1, false, stream);
   if (rc) return rc;
   // side chain, part 2: grad_weight / grad_bias, after GEMM-1

@@ -96,14 +96,12 @@ int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const 
                      hipStream_t stream);
 int build_tap_table_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *table,
                         hipStream_t stream);
-int pack_gout_f32(const Geom &g, const BwdDims &bd, const float *gout, float *ga,
-                  hipStream_t stream);
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, hipStream_t stream);
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
-                      float *gcol, hipStream_t stream);
+                      float *gcol, float *ga, hipStream_t stream);
 int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
                   hipStream_t stream);
 int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *rowptr,
