@@ -112,7 +112,9 @@ def main():
         out = M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo)
         gi, goff, gm, gw, gb = M.modulated_deform_conv2d_backward_cuda(x, w, b, off, m, go, *geo)
         if reducer is not None:
-            reducer(gw, gb)
+            # RCCL all-reduce of grad_weight || grad_bias on a side stream, released as soon as
+            # GEMM-2 / grad_bias are done, i.e. under the grad_input gather of the same backward
+            reducer.reduce_overlapped(gw, gb)
         return out, gi
 
     for _ in range(args.warmup):

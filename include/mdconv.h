@@ -96,6 +96,13 @@ int mdconv_profile_enable(int on);
 int mdconv_profile_read(int which, double *total_ms);
 void mdconv_profile_reset(void);
 
+/* Multi-GPU overlap: every backward records an event on its stream as soon
+ * as grad_weight and grad_bias are final -- before the grad_input gather is enqueued.  This makes
+ * `stream` (a hipStream_t, e.g. the communication stream) wait for that point of the LAST backward
+ * issued by the calling thread, so the all-reduce of grad_weight || grad_bias runs under the rest
+ * of the backward.  Returns MDCONV_EINVAL if this thread has not run a backward yet. */
+int mdconv_stream_wait_weight_ready(void *stream);
+
 /* --- replaces deform_conv2d_forward_cuda (deformable_conv.cu:117-123) ---------------------- */
 int mdconv_deform_conv2d_forward(const mdconv_desc *d, const void *input, const void *weight,
                                  const void *bias, const void *offset, void *output,

@@ -16,6 +16,7 @@ EXPORTS = (
     "mdconv_abi_version", "mdconv_last_error", "mdconv_out_size", "mdconv_workspace_bytes",
     "mdconv_set_path", "mdconv_last_path",
     "mdconv_profile_enable", "mdconv_profile_read", "mdconv_profile_reset",
+    "mdconv_stream_wait_weight_ready",
     "mdconv_deform_conv2d_forward", "mdconv_deform_conv2d_backward",
     "mdconv_modulated_deform_conv2d_forward", "mdconv_modulated_deform_conv2d_backward",
     "mdconv_deform_conv3d_forward", "mdconv_deform_conv3d_backward",
@@ -55,6 +56,8 @@ def lib():
         L.mdconv_profile_enable.restype = ctypes.c_int
         L.mdconv_profile_read.restype = ctypes.c_int
         L.mdconv_profile_reset.restype = None
+        L.mdconv_stream_wait_weight_ready.restype = ctypes.c_int
+        L.mdconv_stream_wait_weight_ready.argtypes = [ctypes.c_void_p]
         for name in EXPORTS[9:]:
             getattr(L, name).restype = ctypes.c_int
         if L.mdconv_abi_version() != 1:
@@ -79,6 +82,14 @@ def last_path():
 
 
 PROFILE_KERNELS = {0: "mfma_fwd_kernel", 1: "mfma_bwd_data_kernel", 2: "mfma_bwd_weight_kernel"}
+
+
+def stream_wait_weight_ready(stream):
+    """Make `stream` (a torch.cuda.Stream) wait until grad_weight / grad_bias of the last backward
+    issued by this thread are final (the grad_input gather may still be running)."""
+    rc = lib().mdconv_stream_wait_weight_ready(ctypes.c_void_p(stream.cuda_stream))
+    if rc != 0:
+        raise RuntimeError(last_error())
 
 
 def profile_enable(on=True):

@@ -14,6 +14,10 @@ namespace mdconv {
 
 static thread_local char g_err[512] = "";
 static thread_local int g_last_path = 0;
+// "grad_weight / grad_bias are final" event of the last backward of this thread
+static thread_local hipEvent_t g_wready = nullptr;
+static thread_local int g_wready_dev = -1;
+static thread_local bool g_wready_set = false;
 static int g_path = -1;  // -1 = not initialised from the environment yet
 
 void set_error(const char *fmt, ...) {
@@ -213,7 +217,31 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
     return mfma_backward(g, d->dtype, t, ws, s);
   }
   g_last_path = MDCONV_PATH_DIRECT;
-  return direct_backward(g, d->dtype, t, s);
+  if ((rc = direct_backward(g, d->dtype, t, s))) return rc;
+  return record_weight_ready(s);
+}
+
+int record_weight_ready(hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MDCONV_ELAUNCH;
+  if (g_wready && dev != g_wready_dev) {
+    (void)hipEventDestroy(g_wready);
+    g_wready = nullptr;
+  }
+  if (!g_wready) {
+    if (hipEventCreateWithFlags(&g_wready, hipEventDisableTiming) != hipSuccess) {
+      g_wready = nullptr;
+      set_error("hipEventCreate failed");
+      return MDCONV_ELAUNCH;
+    }
+    g_wready_dev = dev;
+  }
+  if (hipEventRecord(g_wready, stream) != hipSuccess) {
+    set_error("hipEventRecord failed");
+    return MDCONV_ELAUNCH;
+  }
+  g_wready_set = true;
+  return MDCONV_OK;
 }
 
 }  // namespace mdconv
@@ -238,6 +266,18 @@ size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward) {
   if (current_path() == MDCONV_PATH_DIRECT) return 0;
   if (!mfma_supported(g, d->dtype, backward != 0)) return 0;
   return mfma_workspace_bytes(g, d->dtype, backward != 0);
+}
+
+int mdconv_stream_wait_weight_ready(void *stream) {
+  if (!g_wready_set) {
+    set_error("no backward has been issued by this thread");
+    return MDCONV_EINVAL;
+  }
+  if (hipStreamWaitEvent((hipStream_t)stream, g_wready, 0) != hipSuccess) {
+    set_error("hipStreamWaitEvent failed");
+    return MDCONV_ELAUNCH;
+  }
+  return MDCONV_OK;
 }
 
 int mdconv_set_path(int path) {

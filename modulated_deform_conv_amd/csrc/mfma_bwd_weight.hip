@@ -264,10 +264,11 @@ __global__ __launch_bounds__(256) void reduce_weight_kernel(Geom g, BwdDims bd,
   }
 }
 
-// grad_bias[o] += sum_{b, pix} grad_out[b][o][pix]   (mdeformable_conv.cu:440-444)
-// grid (O, image slices): a few thousand integer-free float atomics in total.
-__global__ __launch_bounds__(256) void grad_bias_kernel(Geom g, const float *__restrict__ gout,
-                                                        float *__restrict__ grad_bias) {
+// grad_bias[o] += sum_{b, pix} grad_out[b][o][pix]   (mdeformable_conv.cu:440-444), in two
+// deterministic stages (no floating-point atomics: the result is bit-identical from run to run):
+// grid (O, slices) partial sums over image slices, then one ordered sum per output channel.
+__global__ __launch_bounds__(256) void grad_bias_partial_kernel(Geom g, const float *__restrict__ gout,
+                                                                float *__restrict__ partial) {
   __shared__ float red[4];
   const int o = blockIdx.x;
   float s = 0.f;
@@ -279,7 +280,16 @@ __global__ __launch_bounds__(256) void grad_bias_kernel(Geom g, const float *__r
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomic_add(grad_bias + o, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[(size_t)blockIdx.y * g.O + o] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void grad_bias_final_kernel(Geom g, int slices,
+                                                              const float *__restrict__ partial,
+                                                              float *__restrict__ grad_bias) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= g.O) return;
+  float s = 0.f;
+  for (int k = 0; k < slices; ++k) s += partial[(size_t)k * g.O + o];
+  grad_bias[o] += s;
 }
 
 int grid_for(int64_t total) {
@@ -325,9 +335,14 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
                      stream, g, bd, part, (float *)t.grad_weight);
   if ((rc = check_launch("reduce_weight"))) return rc;
   if (g.with_bias) {
-    hipLaunchKernelGGL(grad_bias_kernel, dim3(g.O, g.B < 16 ? g.B : 16), dim3(256), 0, stream, g,
-                       (const float *)t.grad_output, (float *)t.grad_bias);
-    rc = check_launch("grad_bias");
+    // the split-K partials are consumed by now: `part` doubles as scratch for the bias partials
+    const int slices = g.B < 16 ? g.B : 16;
+    hipLaunchKernelGGL(grad_bias_partial_kernel, dim3(g.O, slices), dim3(256), 0, stream, g,
+                       (const float *)t.grad_output, part);
+    if ((rc = check_launch("grad_bias_partial"))) return rc;
+    hipLaunchKernelGGL(grad_bias_final_kernel, dim3((g.O + 255) / 256), dim3(256), 0, stream, g,
+                       slices, part, (float *)t.grad_bias);
+    rc = check_launch("grad_bias_final");
   }
   return rc;
 }

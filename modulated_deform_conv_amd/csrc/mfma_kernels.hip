@@ -257,18 +257,19 @@ Side *side_for_current_device() {
 }
 
 // fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`).
-// Two chains, forked onto a side stream and joined before returning:
-//   caller's stream : pack_wq -> GEMM-1 + coordinate gradients ----------> col2im gather
-//   side stream     : CSR build, tap table -> [wait GEMM-1] -> GEMM-2, reduce, bias
-// so the small integer / packing kernels run under GEMM-1 and the HBM-bound col2im gather runs
-// under the MFMA-bound GEMM-2 instead of after it (disjoint workspace regions and gradients).
-// The two GEMMs themselves are kept apart: run concurrently they only halve each other
-// (measured 2.8 + 2.3 ms overlapped vs 1.2 + 1.2 ms back to back).
-// Measured at cfg2 this overlap does NOT pay either: GEMM-1 slows from 1.21 to 1.41 ms next to the
-// small kernels and GEMM-2 from 1.15 to 1.74 ms next to the gather (they compete for the same
-// L2 / texture path), 4.34 vs 4.16 ms per step.  It is therefore off unless MDCONV_SIDE_STREAM=1;
-// with it off both chains are issued in order on the caller's stream.
-int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t stream) {
+// Order on the caller's stream:
+//   tap table, pack_wq -> GEMM-1 (+ coordinate gradients, grad_col, packed grad_out)
+//   -> GEMM-2, split-K reduce, grad_bias -> [weights-ready event] -> CSR build -> col2im gather
+// grad_weight / grad_bias are produced BEFORE the grad_input gather so that a data-parallel
+// all-reduce of them can run under the gather (mdconv_stream_wait_weight_ready).
+//
+// MDCONV_SIDE_STREAM=1 forks the CSR build onto a second stream and runs GEMM-2 there next to the
+// gather.  Measured at cfg2 this overlap does NOT pay: GEMM-1 slows from 1.21 to 1.41 ms next to
+// the small kernels and GEMM-2 from 1.15 to 1.74 ms next to the gather (they compete for the same
+// L2 / texture path), 4.34 vs 4.16 ms per step; the two GEMMs run concurrently only halve each
+// other (2.8 + 2.3 ms).  So it stays an opt-in experiment.
+int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t stream,
+                       bool weights_final) {
   const BwdDims bd = bwd_dims(g);
   float *wq = (float *)(base + bd.off_wq);
   float *ga = (float *)(base + bd.off_ga);
@@ -292,8 +293,10 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
     HIP_OK(hipStreamWaitEvent(s2, sd->fork, 0));
   }
   // side chain, part 1: everything that depends on offset / mask only
-  if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, s2))) return rc;
-  if (sd) HIP_OK(hipEventRecord(sd->csr, s2));
+  if (sd) {
+    if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, s2))) return rc;
+    HIP_OK(hipEventRecord(sd->csr, s2));
+  }
   if ((rc = build_tap_table_f32(g, bd, t, table, s2))) return rc;
   // main chain: grad_offset / grad_mask (+ grad_col)
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
@@ -301,17 +304,29 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, stream);   // also packs grad_out for GEMM-2
   profile_mark(1, false, stream);
   if (rc) return rc;
-  // side chain, part 2: grad_weight / grad_bias, after GEMM-1
+  // grad_weight / grad_bias next, so that a data-parallel all-reduce of them can run under the
+  // grad_input gather (mdconv_stream_wait_weight_ready)
   if (sd) {
     HIP_OK(hipEventRecord(sd->gemm1, stream));
     HIP_OK(hipStreamWaitEvent(s2, sd->gemm1, 0));
   }
   if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, s2))) return rc;
-  if (sd) HIP_OK(hipEventRecord(sd->join, s2));
-  // main chain: grad_input through the inverted scatter map
-  if (sd) HIP_OK(hipStreamWaitEvent(stream, sd->csr, 0));
+  if (sd) {
+    HIP_OK(hipEventRecord(sd->join, s2));
+  } else if (weights_final) {
+    if ((rc = record_weight_ready(stream))) return rc;
+  }
+  // grad_input through the inverted scatter map
+  if (sd) {
+    HIP_OK(hipStreamWaitEvent(stream, sd->csr, 0));
+  } else {
+    if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, stream))) return rc;
+  }
   if ((rc = col2im_f32(g, t, gcol, rowptr, entries, stream))) return rc;
-  if (sd) HIP_OK(hipStreamWaitEvent(stream, sd->join, 0));
+  if (sd) {
+    HIP_OK(hipStreamWaitEvent(stream, sd->join, 0));
+    if (weights_final && (rc = record_weight_ready(stream))) return rc;
+  }
 #undef HIP_OK
   return 0;
 }
@@ -423,7 +438,7 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
       tc.grad_input = base + p.off_gi; tc.grad_offset = base + p.off_goff;
       tc.grad_mask = t.grad_mask ? base + p.off_gm : nullptr;
       tc.grad_weight = base + p.off_gw; tc.grad_bias = base + p.off_gb;
-      if ((rc = backward_chunk_f32(gc, tc, base, stream))) return rc;
+      if ((rc = backward_chunk_f32(gc, tc, base, stream, false))) return rc;
       if ((rc = narrow((const float *)tc.grad_input, (char *)t.grad_input + o_x * es, n_x, true, stream))) return rc;
       if ((rc = narrow((const float *)tc.grad_offset, (char *)t.grad_offset + o_off * es, n_off, true, stream))) return rc;
       if (t.grad_mask &&
@@ -437,12 +452,13 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
       tc.grad_input = (char *)t.grad_input + o_x * es;
       tc.grad_offset = (char *)t.grad_offset + o_off * es;
       tc.grad_mask = t.grad_mask ? (char *)t.grad_mask + o_m * es : nullptr;
-      if ((rc = backward_chunk_f32(gc, tc, base, stream))) return rc;
+      if ((rc = backward_chunk_f32(gc, tc, base, stream, b0 + bc >= g.B))) return rc;
     }
   }
   if (p.half_io) {
     if ((rc = narrow((const float *)(base + p.off_gw), t.grad_weight, n_w, true, stream))) return rc;
     if (g.with_bias && (rc = narrow((const float *)(base + p.off_gb), t.grad_bias, g.O, true, stream))) return rc;
+    if ((rc = record_weight_ready(stream))) return rc;
   }
   return MDCONV_OK;
 }

@@ -44,6 +44,7 @@ class FusedGradAllReduce:
     def __init__(self, group=None):
         self.group = group
         self._flat = None
+        self._comm = None
 
     def _buffer(self, numel, device, dtype):
         dtype = torch.float64 if dtype == torch.float64 else torch.float32   # never below fp32
@@ -70,6 +71,30 @@ class FusedGradAllReduce:
         if async_op:
             return work, finish
         finish()
+        return None
+
+    def reduce_overlapped(self, grad_weight, grad_bias=None):
+        """All-reduce under the tail of the backward that produced the gradients.
+
+        The backward enqueues GEMM-2 / grad_bias BEFORE the grad_input gather and records an event
+        in between (include/mdconv.h: mdconv_stream_wait_weight_ready).  The collective is issued
+        on a communication stream that waits for that event only, so it runs while the gather is
+        still executing; the caller's stream re-joins afterwards ("issue it
+        on a side stream as soon as GEMM-2/bias finish").  Call it right after the backward entry
+        point returned, from the same thread.  CPU tensors (gloo tests) take the plain path."""
+        if not grad_weight.is_cuda:
+            return self(grad_weight, grad_bias)
+        from . import _capi
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        _capi.stream_wait_weight_ready(self._comm)
+        with torch.cuda.stream(self._comm):
+            self(grad_weight, grad_bias)
+        for g in (grad_weight, grad_bias):
+            if g is not None:
+                g.record_stream(self._comm)
+        main.wait_stream(self._comm)
         return None
 
 

@@ -104,3 +104,28 @@ def test_autocast_runs_in_fp32():
     assert_close("autocast", y, m(x.half().float(), off.half().float(), mask), 1e-5)
     y.sum().backward()
     assert x.grad is not None and torch.isfinite(x.grad).all() and ref.shape == y.shape
+
+
+def test_weight_ready_event_orders_a_side_stream():
+    """mdconv_stream_wait_weight_ready: a side stream that waits for the event sees the final
+    grad_weight / grad_bias of the backward just issued (the hook of the overlapped all-reduce)."""
+    from modulated_deform_conv_amd import MDCONV_CUDA as M, _capi
+    case = CASE_BY_NAME["cfg2s_mdcn2d_c64_28x28_b4"]
+    t = make_inputs(case, device="cuda")
+    geo = (3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 64, True)
+    side = torch.cuda.Stream()
+    ref = M.modulated_deform_conv2d_backward_cuda(t["input"], t["weight"], t["bias"], t["offset"],
+                                                  t["mask"], t["grad_output"], *geo)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        gi, goff, gm, gw, gb = M.modulated_deform_conv2d_backward_cuda(
+            t["input"], t["weight"], t["bias"], t["offset"], t["mask"], t["grad_output"], *geo)
+        _capi.stream_wait_weight_ready(side)
+        with torch.cuda.stream(side):
+            gw2, gb2 = gw.clone(), gb.clone()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(gw2, ref[3]) and torch.equal(gb2, ref[4])
+        # grad_input is only reproducible to rounding: the order of a pixel's CSR list depends on
+        # integer-atomic arrival order (the reference's float atomics are no better)
+        assert_close("grad_input", gi, ref[0], 1e-5)
