@@ -19,6 +19,33 @@ def short(name):
     return re.sub(r"\(.*", "", name)
 
 
+def sq_table(src):
+    """MfmaUtil etc. from the SQ / GRBM passes of tools/collect_profiles.sh (sq_counters.txt)."""
+    import ast
+    path = os.path.join(src, "sq_counters.txt")
+    if not os.path.exists(path):
+        return ""
+    rows = collections.defaultdict(dict)
+    for line in open(path):
+        m = re.match(r"^(\S.*?) (\{.*\})\s*$", line)
+        if m:
+            rows[m.group(1)].update({k: float(v) for k, v in ast.literal_eval(m.group(2)).items()})
+    out = ["", "## SQ / GRBM counters (separate `rocprofv3 --pmc` passes, `tools/pmc_kernel.sh`; sums over the chip, per launch)", "",
+           "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); VALU = SQ_INSTS_VALU - SQ_INSTS_MFMA.", "",
+           "| kernel | MFMA instr | other VALU instr | VALU per MFMA | kernel cycles (per XCD) | MfmaUtil | wave time waiting for issue |",
+           "|---|---|---|---|---|---|---|"]
+    for k, v in rows.items():
+        if not v.get("SQ_INSTS_MFMA") or not v.get("GRBM_GUI_ACTIVE"):
+            continue
+        cyc = v["GRBM_GUI_ACTIVE"] / 8
+        valu = v["SQ_INSTS_VALU"] - v["SQ_INSTS_MFMA"]
+        out.append("| %s | %.3g | %.3g | %.2f | %.3g | %.0f %% | %.0f %% |" % (
+            k, v["SQ_INSTS_MFMA"], valu, valu / v["SQ_INSTS_MFMA"], cyc,
+            100 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc),
+            100 * v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"]))
+    return "\n".join(out) + "\n"
+
+
 def main(src, tag):
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out_dir, exist_ok=True)
@@ -75,5 +102,12 @@ def main(src, tag):
     print("wrote profiles/%s_*" % tag)
 
 
+def append_sq(src, tag):
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    with open(os.path.join(out_dir, tag + "_summary.md"), "a") as f:
+        f.write(sq_table(src))
+
+
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
+    append_sq(sys.argv[1], sys.argv[2])
