@@ -219,17 +219,17 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
       // ---- even chunk ----
       commit(tabA, t, Bs);
       __syncthreads();
+      load_a(ra1, t + 1);                   // A first: vmcnt retires in order (see mfma_fwd.hip)
       gather(tabB);                         // chunk t+1
       load_tab(tabA, min(t + 2, t_last));   // chunk t+2
-      load_a(ra1, t + 1);
       __builtin_amdgcn_sched_barrier(0);
       mma(ra0, Bs);
       // ---- odd chunk ----
       commit(tabB, t + 1, Bs + BK * kPitch);
       __syncthreads();
+      load_a(ra0, min(t + 2, t_last));
       gather(tabA);                         // chunk t+2 (or a harmless repeat at the end)
       load_tab(tabB, min(t + 3, t_last));
-      load_a(ra0, min(t + 2, t_last));
       __builtin_amdgcn_sched_barrier(0);
       mma(ra1, Bs + BK * kPitch);
     }

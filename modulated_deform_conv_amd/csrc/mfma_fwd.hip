@@ -227,8 +227,10 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
 #ifndef ABL_NOBARRIER
       __syncthreads();
 #endif
-      issue(rg0, wc0, ntap, nc0);
+      // A first: vmcnt retires in order, so fragments requested AFTER the gathers would make the
+      // MFMAs that need them wait for those gathers as well
       load_a(ra1, a_soff + slab_bytes);
+      issue(rg0, wc0, ntap, nc0);
       __builtin_amdgcn_sched_barrier(0);   // keep every request above the MFMA phase
       mma(ra0, Bs);
       // ---- odd chunk: LDS buffer 1, fragments ra1, gathers rg1 ----
@@ -237,8 +239,8 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       __syncthreads();
 #endif
       a_soff += 2 * slab_bytes;
-      issue(rg1, wc1, ntap, nc0 + BK);
       load_a(ra0, min(a_soff, a_last));
+      issue(rg1, wc1, ntap, nc0 + BK);
       __builtin_amdgcn_sched_barrier(0);
       mma(ra1, Bs + BK * BN);
     }
