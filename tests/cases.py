@@ -49,6 +49,9 @@ CASES = [
     _c("mfma_mdcn3d_g2_dg2_c128_o32", M3, 1, 128, 32, (5, 6, 5), 3, groups=2, dgroups=2, in_step=1, tier="medium", seed=34),
     _c("cfg3s_mdcn2d_c256_g32_dg4_10x10", M2, 2, 256, 256, (10, 10), 3, groups=32, dgroups=4, bias=False, tier="medium", seed=35),
     _c("mfma_dcn2d_dg4_c1024_o16", D2, 1, 1024, 16, (6, 6), 3, dgroups=4, bias=False, tier="medium", seed=36),
+    # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
+    _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
+    _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),
     # medium: down-scaled analogues of BASELINE.json configs[1..4] (same K / stride / dilation /
     # G : DG structure, channel counts that exercise the MFMA tiles incl. ragged edges)
     _c("cfg2s_mdcn2d_c64_28x28_b4", M2, 4, 64, 64, (28, 28), 3, tier="medium", seed=21),
