@@ -386,9 +386,12 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     }
   };
 
-  auto mma = [&](const float4 (&ra)[MB][2], const float *bp) {
+  // `fresh`: first chunk of an iteration in the straight-line K loop -- its first MFMAs take a
+  // literal zero as C (an inline constant of the instruction), which saves zeroing 32 registers
+  auto mma = [&](const float4 (&ra)[MB][2], const float *bp, bool fresh) {
     const float4 b0 = *reinterpret_cast<const float4 *>(bp);
     const float4 b1 = *reinterpret_cast<const float4 *>(bp + 8);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -398,26 +401,26 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
           const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, (fresh && q == 0 && s == 0) ? zero : acc[i], 0, 0, 0);
         }
       }
   };
   // four chunks t .. t+3 of (tap, pass); A runs three chunks ahead (into the next iteration).
   // (Fetching the B fragments a chunk ahead as well was measured slower: 1.24 -> 1.30 ms.)
-  auto quad = [&](int t) {
+  auto quad = [&](int t, bool fresh) {
     const float *bq = Bb + b_cur;
     load_a(ra3, a_off(t + 3));
     __builtin_amdgcn_sched_barrier(0);
-    mma(ra0, bq + t * 16);
+    mma(ra0, bq + t * 16, fresh);
     load_a(ra0, a_off(t + 4));
     __builtin_amdgcn_sched_barrier(0);
-    mma(ra1, bq + (t + 1) * 16);
+    mma(ra1, bq + (t + 1) * 16, false);
     load_a(ra1, a_off(t + 5));
     __builtin_amdgcn_sched_barrier(0);
-    mma(ra2, bq + (t + 2) * 16);
+    mma(ra2, bq + (t + 2) * 16, false);
     load_a(ra2, a_off(t + 6));
     __builtin_amdgcn_sched_barrier(0);
-    mma(ra3, bq + (t + 3) * 16);
+    mma(ra3, bq + (t + 3) * 16, false);
   };
 
   int tile_c = -1;   // tile whose grad_out is in LDS
@@ -455,10 +458,12 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       a_nxt = a_base(tn, pn, q_lo2);
     }
     const int cbase_p = (passp * WAVES_C + wc) * 64;   // channels of the parked accumulators
+    if (QPQ == 0) {
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
+      for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
 
 #pragma unroll
     for (int q = 0; q < NBATCH; ++q) {
@@ -468,9 +473,9 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       __builtin_amdgcn_sched_barrier(0);
       if (QPQ > 0) {
 #pragma unroll
-        for (int jq = 0; jq < QPQ; ++jq) quad((q * QPQ + jq) * 4);
+        for (int jq = 0; jq < QPQ; ++jq) quad((q * QPQ + jq) * 4, q == 0 && jq == 0);
       } else {
-        for (int qd = nq * q / NBATCH; qd < nq * (q + 1) / NBATCH; ++qd) quad(qd * 4);
+        for (int qd = nq * q / NBATCH; qd < nq * (q + 1) / NBATCH; ++qd) quad(qd * 4, false);
       }
       __builtin_amdgcn_sched_barrier(0);
       consume(q, cbase_p, v);
