@@ -250,7 +250,16 @@ def _make_pack(base, name):
 
     if base._modulated:
         def forward(self, x):
-            return base.forward(self, x, self.conv_offset(x), self.conv_mask(x))
+            # ONE side convolution for offset and mask: the two parameter
+            # sets stay separate modules (state_dict keys conv_offset.* / conv_mask.* as in the
+            # reference) and are concatenated along the output channels, so the input is read once
+            # and one library launch replaces two.  Same numbers as two convolutions.
+            co, cm = self.conv_offset, self.conv_mask
+            conv = torch.nn.functional.conv2d if self._nd == 2 else torch.nn.functional.conv3d
+            y = conv(x, torch.cat((co.weight, cm.weight)), torch.cat((co.bias, cm.bias)),
+                     co.stride, co.padding, co.dilation)
+            n_off = co.out_channels
+            return base.forward(self, x, y[:, :n_off].contiguous(), y[:, n_off:].contiguous())
     else:
         def forward(self, x):
             return base.forward(self, x, self.conv_offset(x))

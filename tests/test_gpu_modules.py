@@ -89,6 +89,30 @@ def test_pack_module_runs():
     assert m.conv_offset.weight.grad is not None and m.conv_mask.weight.grad is not None
 
 
+@pytest.mark.parametrize("nd", [2, 3])
+def test_pack_fused_side_conv_equals_two_convs(nd):
+    """The Pack modules run conv_offset and conv_mask as ONE convolution; output and every
+    parameter gradient must equal the reference formulation with two (reference :755-785)."""
+    from modulated_deform_conv_amd import modulated_deform_conv as mdc
+    torch.manual_seed(1)
+    cls = mdc.ModulatedDeformConv2dPack if nd == 2 else mdc.ModulatedDeformConv3dPack
+    base = mdc.ModulatedDeformConv2d if nd == 2 else mdc.ModulatedDeformConv3d
+    m = cls(8, 6, 3, stride=1, padding=1, deformable_groups=2, bias=True).cuda()
+    assert set(k.split(".")[0] for k in m.state_dict()) == {"weight", "bias", "conv_offset", "conv_mask"}
+    x = torch.randn(2, 8, *([7] * nd), device="cuda", requires_grad=True)
+    y = m(x)
+    y.square().sum().backward()
+    got = [x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+    x.grad = None
+    m.zero_grad()
+    y2 = base.forward(m, x, m.conv_offset(x), m.conv_mask(x))
+    y2.square().sum().backward()
+    want = [x.grad] + [p.grad for p in m.parameters()]
+    assert_close("output", y, y2, 1e-5)
+    for a, b in zip(got, want):
+        assert_close("grad", a, b, 1e-4)
+
+
 def test_autocast_runs_in_fp32():
     """AMP integration: under autocast the op computes in fp32 and returns fp32."""
     from modulated_deform_conv_amd import modulated_deform_conv as mdc
