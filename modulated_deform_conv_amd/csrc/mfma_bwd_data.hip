@@ -557,6 +557,12 @@ __global__ __launch_bounds__(256) void csr_pass_kernel(Geom g, const float *__re
   }
 }
 
+// counters are cleared by a kernel, not hipMemsetAsync (keeps the whole backward a plain sequence of
+// kernel nodes under HIP graph capture)
+__global__ __launch_bounds__(256) void zero_int_kernel(int *__restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
+}
+
 // exclusive scan of cnt[seg][0..S_i) -> rowptr[seg][0..S_i], one workgroup per segment
 __global__ __launch_bounds__(256) void csr_scan_kernel(int S_i, const int *__restrict__ cnt,
                                                        int *__restrict__ rowptr) {
@@ -819,8 +825,10 @@ int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *
                   hipStream_t stream) {
   const int64_t samples = (int64_t)g.B * g.DG * g.K * g.S_o;
   const size_t cnt_bytes = (size_t)g.B * g.DG * g.S_i * sizeof(int);
-  hipError_t e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
+  const int64_t cnt_n = (int64_t)(cnt_bytes / sizeof(int));
+  hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
+  int rc = check_launch("zero_cnt");
+  if (rc) return rc;
 #define LAUNCH_CSR(ND, MOD, FILL)                                                               \
   hipLaunchKernelGGL((csr_pass_kernel<ND, MOD, FILL>), dim3(grid_for(samples)), dim3(256), 0,   \
                      stream, g, (const float *)t.offset, (const float *)t.mask, cnt, rowptr,    \
@@ -831,12 +839,11 @@ int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *
     else { if (g.modulated) LAUNCH_CSR(3, true, FILL); else LAUNCH_CSR(3, false, FILL); }      \
   } while (0)
   LAUNCH_CSR2(false);
-  int rc = check_launch("csr_count");
-  if (rc) return rc;
+  if ((rc = check_launch("csr_count"))) return rc;
   hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B * g.DG), dim3(256), 0, stream, g.S_i, cnt, rowptr);
   if ((rc = check_launch("csr_scan"))) return rc;
-  e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
+  hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
+  if ((rc = check_launch("zero_cnt"))) return rc;
   LAUNCH_CSR2(true);
   return check_launch("csr_fill");
 #undef LAUNCH_CSR2

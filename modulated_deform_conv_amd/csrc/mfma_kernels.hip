@@ -221,11 +221,18 @@ int narrow(const float *src, void *dst, int64_t n, bool accum, hipStream_t s) {
     hipLaunchKernelGGL(narrow_kernel<false>, dim3(nblocks(n)), dim3(256), 0, s, src, (__half *)dst, n);
   return check_launch("narrow");
 }
-int zero(void *p, size_t bytes, hipStream_t s) {
+// cleared by a kernel rather than hipMemsetAsync: memset nodes made HIP graph replay fault
+// (tools/graph_check.py), and a plain kernel sequence captures cleanly
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned *__restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0u;
+}
+int zero(void *p, size_t bytes, hipStream_t s) {   // bytes is a multiple of 4 (fp32 buffers)
   if (bytes == 0) return MDCONV_OK;
-  const hipError_t e = hipMemsetAsync(p, 0, bytes, s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
-  return MDCONV_OK;
+  const int64_t n = (int64_t)(bytes / 4);
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, s,
+                     (unsigned *)p, n);
+  return check_launch("zero");
 }
 
 // A second stream per device for the fork/join inside the backward.

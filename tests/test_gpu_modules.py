@@ -153,3 +153,31 @@ def test_weight_ready_event_orders_a_side_stream():
         # grad_input is only reproducible to rounding: the order of a pixel's CSR list depends on
         # integer-atomic arrival order (the reference's float atomics are no better)
         assert_close("grad_input", gi, ref[0], 1e-5)
+
+
+@pytest.mark.parametrize("name", ["cfg2s_mdcn2d_c64_28x28_b4", "cfg4s_dcn3d_c16_12cubed_b2",
+                                  "mfma_mdcn2d_g4_dg2_c128_o64"])
+def test_hip_graph_capture_and_replay(name):
+    """Forward + backward are a plain sequence of kernel launches on the caller's stream (no
+    memset nodes, no host synchronisation), so they capture into a HIP graph; the replay must
+    reproduce the eager results."""
+    from tests.util import run_product
+    case = CASE_BY_NAME[name]
+    t = make_inputs(case, device="cuda")
+    ref_out, ref_g, paths = run_product(case, t, "auto")
+    assert paths[1] == "mfma"
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        run_product(case, t, "auto")
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out, g, _ = run_product(case, t, "auto")
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert_close("output", out, ref_out, 1e-6)
+    for k, v in g.items():
+        if v is not None and ref_g[k] is not None:
+            assert_close(k, v, ref_g[k], 1e-5)
