@@ -15,12 +15,37 @@
 //   direct_bwd_weight : grad_weight / grad_bias, per-thread register tile, wave-shuffle + LDS
 //                       block reduction, one atomic per (block, element).
 #include "mdconv_common.hpp"
+#include "mfma_tile.hpp"   // raw buffer loads
 
 namespace mdconv {
 
 namespace {
 
 constexpr int kThreads = 256;
+
+// The two neighbours along the contiguous axis in ONE load (see make_pairs): 4 bytes for half,
+// 8 for float, 16 for double.  Raw buffer loads take any element-aligned byte offset.
+template <typename T> struct PairLoad;
+template <> struct PairLoad<float> {
+  static __device__ __forceinline__ void ld(rsrc_t r, unsigned voff, float &x, float &y) {
+    const float2 v = buf_load2(r, (int)voff, 0);
+    x = v.x; y = v.y;
+  }
+};
+template <> struct PairLoad<__half> {
+  static __device__ __forceinline__ void ld(rsrc_t r, unsigned voff, float &x, float &y) {
+    const unsigned bits = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0);
+    x = __half2float(__ushort_as_half((unsigned short)(bits & 0xffffu)));
+    y = __half2float(__ushort_as_half((unsigned short)(bits >> 16)));
+  }
+};
+template <> struct PairLoad<double> {
+  static __device__ __forceinline__ void ld(rsrc_t r, unsigned voff, double &x, double &y) {
+    struct D2 { double x, y; };
+    const D2 v = __builtin_bit_cast(D2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+    x = v.x; y = v.y;
+  }
+};
 
 template <typename T, int ND, bool MOD, typename A>
 __device__ __forceinline__ void load_tap(const Geom &g, const T *offset, const T *mask, int b,
@@ -39,7 +64,10 @@ __device__ __forceinline__ void load_tap(const Geom &g, const T *offset, const T
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <typename T, int ND, bool MOD, int TO>
+// PAIR: fetch the corner pairs of the contiguous axis with one load each (2^(ND-1) gathers per
+// sample instead of 2^ND: the kernel is bound by gather instructions, cfg3 shape 0.61 -> see
+// DESIGN.md); needs >= 2 columns and an input tensor below 4 GiB (32-bit buffer offsets).
+template <typename T, int ND, bool MOD, int TO, bool PAIR>
 __global__ __launch_bounds__(kThreads) void direct_fwd_kernel(Geom g, int CC, const T *__restrict__ input,
                                                               const T *__restrict__ weight,
                                                               const T *__restrict__ bias,
@@ -63,6 +91,8 @@ __global__ __launch_bounds__(kThreads) void direct_fwd_kernel(Geom g, int CC, co
   A acc[TO];
 #pragma unroll
   for (int t = 0; t < TO; ++t) acc[t] = (A)0;
+  constexpr int NP = 1 << (ND - 1);
+  const rsrc_t r_in = make_rsrc(input, (size_t)g.B * g.C * g.S_i * sizeof(T));
 
   for (int c0 = 0; c0 < g.Cg; c0 += CC) {
     const int cc_n = min(CC, g.Cg - c0);
@@ -78,19 +108,32 @@ __global__ __launch_bounds__(kThreads) void direct_fwd_kernel(Geom g, int CC, co
       int cur_dg = -1;
       TapCoef<ND, A> tc;
       A m = (A)1;
+      int pidx[NP];
+      A px[NP], py[NP];
       for (int cc = 0; cc < cc_n; ++cc) {
         const int c = grp * g.Cg + c0 + cc;
         const int dg = c / g.Cdg;
         if (dg != cur_dg) {
           load_tap<T, ND, MOD, A>(g, offset, mask, b, dg, tap, pix, o, false, tc, m);
+          if (PAIR) make_pairs<ND, A>(g, tc, m, pidx, px, py);   // mask folded into the weights
           cur_dg = dg;
         }
-        const T *plane = input + (int64_t)(b * g.C + c) * g.S_i;
         A val = (A)0;
+        if (PAIR) {
+          const unsigned plane_off = (unsigned)(b * g.C + c) * (unsigned)g.S_i;
 #pragma unroll
-        for (int ci = 0; ci < (1 << ND); ++ci)
-          val += corner_weight<ND, A>(tc, ci) * (A)ld(plane + corner_index<ND, A>(tc, ci));
-        val *= m;
+          for (int pi = 0; pi < NP; ++pi) {
+            A x, y;
+            PairLoad<T>::ld(r_in, (plane_off + (unsigned)pidx[pi]) * (unsigned)sizeof(T), x, y);
+            val += px[pi] * x + py[pi] * y;
+          }
+        } else {
+          const T *plane = input + (int64_t)(b * g.C + c) * g.S_i;
+#pragma unroll
+          for (int ci = 0; ci < (1 << ND); ++ci)
+            val += corner_weight<ND, A>(tc, ci) * (A)ld(plane + corner_index<ND, A>(tc, ci));
+          val *= m;
+        }
         const A *wrow = Ws + (cc * g.K + tap) * TO;
 #pragma unroll
         for (int t = 0; t < TO; ++t) acc[t] += wrow[t] * val;
@@ -341,9 +384,16 @@ int launch_fwd(const Geom &g, const Tensors &t, hipStream_t stream) {
   }
   const int otiles = (g.Og + TO - 1) / TO;
   dim3 grid((g.N + kThreads - 1) / kThreads, g.G * otiles);
-  hipLaunchKernelGGL((direct_fwd_kernel<T, ND, MOD, TO>), grid, dim3(kThreads), smem, stream, g, cc,
-                     (const T *)t.input, (const T *)t.weight, (const T *)t.bias,
-                     (const T *)t.offset, (const T *)t.mask, (T *)t.output);
+  const bool pair = g.in_sz[g.nd - 1] >= 2 &&
+                    (size_t)g.B * g.C * g.S_i * sizeof(T) < 0xfffffff0ull;
+  if (pair)
+    hipLaunchKernelGGL((direct_fwd_kernel<T, ND, MOD, TO, true>), grid, dim3(kThreads), smem, stream, g,
+                       cc, (const T *)t.input, (const T *)t.weight, (const T *)t.bias,
+                       (const T *)t.offset, (const T *)t.mask, (T *)t.output);
+  else
+    hipLaunchKernelGGL((direct_fwd_kernel<T, ND, MOD, TO, false>), grid, dim3(kThreads), smem, stream, g,
+                       cc, (const T *)t.input, (const T *)t.weight, (const T *)t.bias,
+                       (const T *)t.offset, (const T *)t.mask, (T *)t.output);
   return check_launch("direct_fwd");
 }
 
