@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
-    float *__restrict__ ga, int ntiles, int n_full, int n_tail) {
+    float *__restrict__ ga, int *__restrict__ cnt, int ntiles, int n_full, int n_tail) {
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   // group the corner sums run on over the passes and only the WAVES_C waves are reduced.
   const bool per_block = g.DG > 1;
   const int nblk = per_block ? passes * WAVES_C : WAVES_C;
+  const int bpd = per_block ? g.Cdg / 64 : nblk;   // 64-channel blocks per deformable group
   const int frag_bytes = 64 * 16;                      // one [lane][4] fragment
   const int chunk_bytes = bd.cblks_q * 2 * frag_bytes; // one ochunk of wq
   const rsrc_t r_in = make_rsrc(input, (size_t)g.B * g.C * g.S_i * 4);
@@ -265,12 +266,21 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     for (int r = 0; r < 16; ++r) accp[i][r] = 0.f;
 
   // ---- sampling state of (tapp, parked pixel): corner PAIRS (make_pairs) ----
-  auto new_tap_state = [&](int tapp) {
+  // `count`: this wave is the one that also counts the scatter targets of (tapp, pixel) for the
+  // inverted scatter map (first pass of the CSR build, csr_pass_kernel<.., false> otherwise):
+  // fire-and-forget integer atomics that disappear under the MFMAs.
+  auto new_tap_state = [&](int tapp, int dgp, bool count) {
     int tcd[ND];
     tap_coords<ND>(g, tapp, tcd);
     TapCoef<ND, float> tc;
     make_tap<ND, float>(g, pp.oc, tcd, delta_n, true, tc);
     mg = (!g.range_gate || tc.inside) ? m_n : 0.f;
+    if (count && kh == 0 && pp.live) {
+      int *cseg = cnt + ((int64_t)pp.b * g.DG + dgp) * g.S_i;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci)
+        if (corner_weight_atom<ND, float>(tc, ci) != 0.f) atomicAdd(cseg + corner_index<ND, float>(tc, ci), 1);
+    }
     int pidx[NP];
     float px[NP], py[NP];
     make_pairs<ND, float>(g, tc, 1.f, pidx, px, py);
@@ -338,7 +348,6 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   // ---- tap `tapp` of the parked tile is complete for this wave's channels: reduce, park in
   // LDS; `flush` (end of a tap group / of the tile / of the unit range) writes the group out ----
   int grp_lo = (u0 % g.K) % kTapGroup;   // first slot of the current tap group held in `red`
-  const int bpd = per_block ? g.Cdg / 64 : nblk;   // 64-channel blocks per deformable group
   auto finish_tap = [&](int tapp, int blk, bool flush_ok, bool last) {
     float goff[ND], gm = 0.f;
 #pragma unroll
@@ -427,7 +436,11 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   int tapp = 0, passp = 0;   // (tap, pass) of the parked accumulators
   int tile = u0 / g.K, tap = u0 - tile * g.K, pass = 0;   // of the running K loop
   for (int it = 0; it < iters; ++it) {
-    if (it > 0 && (passp == 0 || per_block)) new_tap_state(tapp);
+    if (it > 0 && (passp == 0 || per_block)) {
+      const int blk = passp * WAVES_C + wc;
+      if (per_block) new_tap_state(tapp, min(blk * 64, g.C - 1) / g.Cdg, blk % bpd == 0 && blk * 64 < g.C);
+      else new_tap_state(tapp, 0, wc == 0);
+    }
     if (tile != tile_c) {
       if (tile_c >= 0) __syncthreads();   // every wave is done with the previous tile's K loops
       load_gout_tile(tile);
@@ -498,7 +511,11 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   }
   // ---- drain of the last iteration ----
   {
-    if (passp == 0 || per_block) new_tap_state(tapp);
+    if (passp == 0 || per_block) {
+      const int blk = passp * WAVES_C + wc;
+      if (per_block) new_tap_state(tapp, min(blk * 64, g.C - 1) / g.Cdg, blk % bpd == 0 && blk * 64 < g.C);
+      else new_tap_state(tapp, 0, wc == 0);
+    }
     const int cbase_p = (passp * WAVES_C + wc) * 64;
 #pragma unroll
     for (int q = 0; q < NBATCH; ++q) {
@@ -780,7 +797,9 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
 }
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
-                      float *gcol, float *ga, hipStream_t stream) {
+                      float *gcol, float *ga, int *cnt, hipStream_t stream) {
+  // cnt: per-(image, deformable group, input pixel) counters (zeroed by csr_zero_f32), counted
+  // by GEMM-1 (CSR pass 1)
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
   do {                                                                                          \
     const int bnp = 32 * (4 / WC);                                                              \
@@ -801,7 +820,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
-                       (float *)t.grad_offset, (float *)t.grad_mask, ga, ntiles, n_full, n_tail); \
+                       (float *)t.grad_offset, (float *)t.grad_mask, ga, cnt, ntiles, n_full, n_tail); \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \
@@ -821,33 +840,30 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
   return check_launch("mfma_bwd_data");
 }
 
+int csr_zero_f32(const Geom &g, int *cnt, hipStream_t stream) {
+  const int64_t cnt_n = (int64_t)g.B * g.DG * g.S_i;
+  hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
+  return check_launch("zero_cnt");
+}
+
+// second half of the CSR build (the counting pass ran inside GEMM-1): scan -> fill
 int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
                   hipStream_t stream) {
   const int64_t samples = (int64_t)g.B * g.DG * g.K * g.S_o;
-  const size_t cnt_bytes = (size_t)g.B * g.DG * g.S_i * sizeof(int);
-  const int64_t cnt_n = (int64_t)(cnt_bytes / sizeof(int));
-  hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
-  int rc = check_launch("zero_cnt");
-  if (rc) return rc;
-#define LAUNCH_CSR(ND, MOD, FILL)                                                               \
-  hipLaunchKernelGGL((csr_pass_kernel<ND, MOD, FILL>), dim3(grid_for(samples)), dim3(256), 0,   \
-                     stream, g, (const float *)t.offset, (const float *)t.mask, cnt, rowptr,    \
-                     (int2 *)entries)
-#define LAUNCH_CSR2(FILL)                                                                       \
-  do {                                                                                          \
-    if (g.nd == 2) { if (g.modulated) LAUNCH_CSR(2, true, FILL); else LAUNCH_CSR(2, false, FILL); } \
-    else { if (g.modulated) LAUNCH_CSR(3, true, FILL); else LAUNCH_CSR(3, false, FILL); }      \
-  } while (0)
-  LAUNCH_CSR2(false);
-  if ((rc = check_launch("csr_count"))) return rc;
+  const int64_t cnt_n = (int64_t)g.B * g.DG * g.S_i;
+  int rc;
   hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B * g.DG), dim3(256), 0, stream, g.S_i, cnt, rowptr);
   if ((rc = check_launch("csr_scan"))) return rc;
   hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
   if ((rc = check_launch("zero_cnt"))) return rc;
-  LAUNCH_CSR2(true);
-  return check_launch("csr_fill");
-#undef LAUNCH_CSR2
+#define LAUNCH_CSR(ND, MOD)                                                                     \
+  hipLaunchKernelGGL((csr_pass_kernel<ND, MOD, true>), dim3(grid_for(samples)), dim3(256), 0,   \
+                     stream, g, (const float *)t.offset, (const float *)t.mask, cnt, rowptr,    \
+                     (int2 *)entries)
+  if (g.nd == 2) { if (g.modulated) LAUNCH_CSR(2, true); else LAUNCH_CSR(2, false); }
+  else { if (g.modulated) LAUNCH_CSR(3, true); else LAUNCH_CSR(3, false); }
 #undef LAUNCH_CSR
+  return check_launch("csr_fill");
 }
 
 int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *rowptr,

@@ -4,7 +4,6 @@
 
 #include <stdlib.h>
 
-#include <mutex>
 #include <vector>
 
 namespace mdconv {
@@ -235,46 +234,17 @@ int zero(void *p, size_t bytes, hipStream_t s) {   // bytes is a multiple of 4 (
   return check_launch("zero");
 }
 
-// A second stream per device for the fork/join inside the backward.
-struct Side {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, csr = nullptr, gemm1 = nullptr, join = nullptr;
-  bool ok = false;
-  std::mutex enqueue;   // one backward at a time records / waits on the three events
-};
-Side *side_for_current_device() {
-  static Side sides[64];
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  Side &sd = sides[dev];
-  if (!sd.stream) {
-    // opt-in: at cfg2 the fork/join LOSES (4.34 vs 4.16 ms per step) -- see backward_chunk_f32
-    const char *e = getenv("MDCONV_SIDE_STREAM");
-    if (!e || atoi(e) == 0) return nullptr;
-    if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) == hipSuccess &&
-        hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&sd.csr, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&sd.gemm1, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess)
-      sd.ok = true;
-  }
-  return sd.ok ? &sd : nullptr;
-}
-
 // fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`).
 // Order on the caller's stream:
-//   tap table, pack_wq -> GEMM-1 (+ coordinate gradients, grad_col, packed grad_out)
-//   -> GEMM-2, split-K reduce, grad_bias -> [weights-ready event] -> CSR build -> col2im gather
+//   tap table, pack_wq, zero counters
+//   -> GEMM-1 (+ coordinate gradients, grad_col, packed grad_out, CSR counting pass)
+//   -> GEMM-2, split-K reduce, grad_bias -> [weights-ready event] -> CSR scan + fill -> col2im
 // grad_weight / grad_bias are produced BEFORE the grad_input gather so that a data-parallel
 // all-reduce of them can run under the gather (mdconv_stream_wait_weight_ready).
-//
-// MDCONV_SIDE_STREAM=1 forks the CSR build onto a second stream and runs GEMM-2 there next to the
-// gather.  Measured at cfg2 this overlap does NOT pay: GEMM-1 slows from 1.21 to 1.41 ms next to
-// the small kernels and GEMM-2 from 1.15 to 1.74 ms next to the gather (they compete for the same
-// L2 / texture path), 4.34 vs 4.16 ms per step; the two GEMMs run concurrently only halve each
-// other (2.8 + 2.3 ms).  So it stays an opt-in experiment.
+// Stream-level overlap was tried and dropped: forking the CSR build to a second stream and
+// running GEMM-2 next to the gather slowed GEMM-1 from 1.21 to 1.41 ms and GEMM-2 from 1.15 to
+// 1.74 ms (they compete for the same L2 / texture path; 4.34 vs 4.16 ms per step at cfg2), and
+// the two GEMMs run concurrently only halve each other.
 int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t stream,
                        bool weights_final) {
   const BwdDims bd = bwd_dims(g);
@@ -285,57 +255,18 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   float *gcol = (float *)(base + bd.off_gcol);
   int *cnt = (int *)(base + bd.off_cnt), *rowptr = (int *)(base + bd.off_rowptr);
   void *entries = base + bd.off_entries;
-  Side *sd = side_for_current_device();
-  hipStream_t s2 = sd ? sd->stream : stream;
-  std::unique_lock<std::mutex> lock;
-  if (sd) lock = std::unique_lock<std::mutex>(sd->enqueue);
   int rc;
-#define HIP_OK(x)                                                                     \
-  do {                                                                                \
-    hipError_t e_ = (x);                                                              \
-    if (e_ != hipSuccess) { set_error(#x ": %s", hipGetErrorString(e_)); return MDCONV_ELAUNCH; } \
-  } while (0)
-  if (sd) {
-    HIP_OK(hipEventRecord(sd->fork, stream));
-    HIP_OK(hipStreamWaitEvent(s2, sd->fork, 0));
-  }
-  // side chain, part 1: everything that depends on offset / mask only
-  if (sd) {
-    if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, s2))) return rc;
-    HIP_OK(hipEventRecord(sd->csr, s2));
-  }
-  if ((rc = build_tap_table_f32(g, bd, t, table, s2))) return rc;
-  // main chain: grad_offset / grad_mask (+ grad_col)
+  if ((rc = build_tap_table_f32(g, bd, t, table, stream))) return rc;
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
+  if ((rc = csr_zero_f32(g, cnt, stream))) return rc;
   profile_mark(1, true, stream);
-  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, stream);   // also packs grad_out for GEMM-2
+  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, cnt, stream);
   profile_mark(1, false, stream);
   if (rc) return rc;
-  // grad_weight / grad_bias next, so that a data-parallel all-reduce of them can run under the
-  // grad_input gather (mdconv_stream_wait_weight_ready)
-  if (sd) {
-    HIP_OK(hipEventRecord(sd->gemm1, stream));
-    HIP_OK(hipStreamWaitEvent(s2, sd->gemm1, 0));
-  }
-  if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, s2))) return rc;
-  if (sd) {
-    HIP_OK(hipEventRecord(sd->join, s2));
-  } else if (weights_final) {
-    if ((rc = record_weight_ready(stream))) return rc;
-  }
-  // grad_input through the inverted scatter map
-  if (sd) {
-    HIP_OK(hipStreamWaitEvent(stream, sd->csr, 0));
-  } else {
-    if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, stream))) return rc;
-  }
-  if ((rc = col2im_f32(g, t, gcol, rowptr, entries, stream))) return rc;
-  if (sd) {
-    HIP_OK(hipStreamWaitEvent(stream, sd->join, 0));
-    if (weights_final && (rc = record_weight_ready(stream))) return rc;
-  }
-#undef HIP_OK
-  return 0;
+  if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, stream))) return rc;
+  if (weights_final && (rc = record_weight_ready(stream))) return rc;
+  if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, stream))) return rc;
+  return col2im_f32(g, t, gcol, rowptr, entries, stream);
 }
 
 }  // namespace

@@ -101,7 +101,8 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
-                      float *gcol, float *ga, hipStream_t stream);
+                      float *gcol, float *ga, int *cnt, hipStream_t stream);
+int csr_zero_f32(const Geom &g, int *cnt, hipStream_t stream);
 int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
                   hipStream_t stream);
 int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *rowptr,
