@@ -52,6 +52,15 @@ CASES = [
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),
+    # kernel shapes / strides the MFMA kernels must also get right: 1x1, 5x5 stride 2 (25 taps =
+    # three tap groups), rectangular, large dilation, anisotropic 3-D
+    _c("mfma_mdcn2d_k1_c64_o32", M2, 2, 64, 32, (9, 11), 1, padding=0, tier="medium", seed=41),
+    _c("mfma_dcn2d_k5_s2_c32_o64", D2, 2, 32, 64, (17, 15), 5, stride=2, padding=2, tier="medium", seed=42),
+    _c("mfma_mdcn2d_k3x1_dil3_c48_o40", M2, 2, 48, 40, (13, 12), (3, 1), padding=(3, 0), dilation=(3, 1),
+       bias=False, tier="medium", seed=43),
+    _c("mfma_dcn3d_k1x3x3_s2_c32_o32", D3, 1, 32, 32, (4, 9, 10), (1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1),
+       tier="medium", seed=44),
+    _c("mfma_mdcn2d_big_offsets_c32", M2, 2, 32, 32, (8, 9), 3, tier="medium", seed=45, offset_scale=5.0),
     # medium: down-scaled analogues of BASELINE.json configs[1..4] (same K / stride / dilation /
     # G : DG structure, channel counts that exercise the MFMA tiles incl. ragged edges)
     _c("cfg2s_mdcn2d_c64_28x28_b4", M2, 4, 64, 64, (28, 28), 3, tier="medium", seed=21),
