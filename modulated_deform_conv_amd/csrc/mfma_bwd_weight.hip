@@ -14,6 +14,8 @@
 //     sampling state of (tap, pixel) changes every chunk, so it is NOT recomputed here (that
 //     would be ~60 VALU per chunk) but read from the per-call `tap table` (byte offsets + weights
 //     of the 2^ND corners, built by `build_tap_table`), two chunks ahead;
+//     (gathering two chunks ahead with double-buffered corner registers was measured SLOWER:
+//     1.14 -> 1.24 ms at cfg2);
 //   * LDS holds only the B slab (double buffered, pitch 33 so the transposing write is at most
 //     2-way conflicted, which is free for ds_write_b32).
 #include "mfma_kernels.hpp"
