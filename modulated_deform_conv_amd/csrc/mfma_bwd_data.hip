@@ -6,19 +6,22 @@
 // ds_add_f32 is no better (4.7 ms) -- against a 2.3 ms MFMA budget for the whole iteration.
 // So nothing here uses floating-point atomics:
 //
-//  1. mfma_bwd_data_kernel  (col2im_coord + GEMM-1, fused)
+//  1. mfma_bwd_data_kernel  (col2im_coord + GEMM-1, fused; details above the kernel)
 //     M = input channels, N = output pixels, K = output channels.  A = W pre-packed in
-//     MFMA-fragment order (`pack_wq`), B = grad_out slab through LDS.  In the accumulator layout
-//     a lane owns ONE pixel and 32 channels, so grad_offset / grad_mask -- sums over channels of
-//     grad_col * d(sample) -- are reduced in registers, then across the two half-waves with one
-//     shuffle and across channel-waves through LDS, and written once per (tap, pixel) by their
-//     single owner.  grad_col itself is streamed to the workspace CHANNEL-INNERMOST,
-//     [b][tap][pix][c] (16-byte stores: a lane holds 4 consecutive channels), for step 3.
-//  2. build_scatter_csr  (count -> scan -> fill, integer atomics only)
-//     inverts the scatter map: for every (image, input pixel q) the list of
+//     MFMA-fragment order (`pack_wq`, block-diagonal dense for conv groups), B = the grad_out
+//     tile, resident in LDS for all taps.  In the accumulator layout a lane owns ONE pixel and
+//     32 channels, so grad_offset / grad_mask -- sums over channels of grad_col * d(sample) --
+//     are reduced in registers, then across the two half-waves with one shuffle and across the
+//     64-channel blocks of a deformable group through LDS, and written once per
+//     (group, tap, pixel) by their single owner.  grad_col itself is streamed to the workspace
+//     CHANNEL-INNERMOST, [b][tap][pix][c] (16-byte stores: a lane holds 4 consecutive
+//     channels), for step 3.  The kernel also emits grad_out in the fragment order GEMM-2 wants
+//     and runs the counting pass of step 2.
+//  2. inverted scatter map  (count [inside step 1] -> scan -> fill, integer atomics only):
+//     for every (image, deformable group, input pixel q) the list of
 //     (tap * S_o + output pixel, bilinear weight * mask) that land on q.  Depends only on
 //     offset / mask.
-//  3. col2im_gather_kernel
+//  3. col2im_gather_kernel / col2im_gather_grouped_kernel
 //     grad_input[b][c][q] += sum over the lists of q of weight * grad_col[b][tap][n][c]:
 //     one WAVE per input pixel q, lanes = channels (4 each), so every list entry is one
 //     wave-uniform scalar read plus one fully coalesced 16 B/lane vector read of all channels --
