@@ -18,12 +18,17 @@ from tests.cases import CASE_BY_NAME, make_inputs  # noqa: E402
 
 GOLDEN_CASES = ["cfg1_dcn2d_c4_8x8_b1", "dcn2d_s2_g2_dg2", "mdcn2d_s2_g4_dg2", "mdcn2d_big_offsets",
                 "mdcn2d_rect_params", "dcn3d_s2_g2", "mdcn3d_basic", "mfma_mdcn2d_c32_o48_9x10",
-                "mfma_dcn3d_c16_o16_5x6x5"]
+                "mfma_dcn3d_c16_o16_5x6x5",
+                # conv groups + deformable groups on the MFMA backward
+                "mfma_dcn2d_g2_c32_o32", "mfma_mdcn2d_g8_dg2_c256_o32"]
+ONLY_NEW = "--new" in sys.argv   # write only fixtures that do not exist yet
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     for name in GOLDEN_CASES:
+        if ONLY_NEW and os.path.exists(os.path.join(out_dir, name + ".pt")):
+            continue
         case = CASE_BY_NAME[name]
         t32 = make_inputs(case, dtype=torch.float32)             # the exact fp32 inputs the tests use
         t = {k: (None if v is None else v.double()) for k, v in t32.items()}
