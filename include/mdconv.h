@@ -22,7 +22,8 @@
  *  - Backward entry points ACCUMULATE into every grad_* buffer, which is what the reference's
  *    caller-allocated entry points do (deformable_conv.cu:327-333; the Python wrapper zero-fills,
  *    modulated_deform_conv.py:53-56).  For the modulated-2D op, whose reference entry point
- *    allocates zeros itself (mdeformable_conv.cu:404-411), the binding passes zeroed buffers.
+ *    allocates zeros itself (mdeformable_conv.cu:404-411), the binding passes uninitialised
+ *    buffers and switches the call to overwrite mode (mdconv_set_accumulate).
  *  - `in_step` is accepted for signature parity (reference README.md:30-31) and validated
  *    (> 0); results never depend on it (the reference's own modulated-2D op is in_step-invariant).
  *  - Return value: 0 on success, a negative MDCONV_E* code otherwise; mdconv_last_error() gives
@@ -95,6 +96,12 @@ int mdconv_last_path(void);
 int mdconv_profile_enable(int on);
 int mdconv_profile_read(int which, double *total_ms);
 void mdconv_profile_reset(void);
+
+/* Backward write mode of the calling thread: 1 (default) = ACCUMULATE into grad_* like the
+ * reference's caller-allocated entry points; 0 = OVERWRITE grad_* (buffers need not be
+ * initialised: saves the caller's zero-fills and the read half of every read-modify-write).
+ * Returns the previous mode. */
+int mdconv_set_accumulate(int on);
 
 /* Multi-GPU overlap: every backward records an event on its stream as soon
  * as grad_weight and grad_bias are final -- before the grad_input gather is enqueued.  This makes

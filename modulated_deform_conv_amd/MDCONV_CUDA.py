@@ -199,17 +199,21 @@ def modulated_deform_conv2d_backward_cuda(input, weight, bias, offset, mask, gra
               (dilation_h, dilation_w), group, deformable_group, in_step, with_bias)
     osz = _out_shape(d, 2)
     _check_side(d, 2, kernel_h * kernel_w, offset, mask, grad_output, "grad_output", osz)
-    grad_input = torch.zeros_like(input)          # mdeformable_conv.cu:404-411
-    grad_offset = torch.zeros_like(offset)
-    grad_mask = torch.zeros_like(mask)
-    grad_weight = torch.zeros_like(weight)
-    grad_bias = torch.zeros_like(bias)
+    # the reference allocates zeros here (mdeformable_conv.cu:404-411) and adds into them; this
+    # entry point owns its results, so it allocates uninitialised memory and asks the library to
+    # WRITE the gradients (no zero fills, no read-modify-write)
+    grad_input = torch.empty_like(input)
+    grad_offset = torch.empty_like(offset)
+    grad_mask = torch.empty_like(mask)
+    grad_weight = torch.empty_like(weight)
+    grad_bias = torch.empty_like(bias)
     _backward_checks(input, weight, offset, mask, grad_input, grad_weight, grad_bias, grad_offset,
                      grad_mask, grad_output, d, with_bias)
-    _run("mdconv_modulated_deform_conv2d_backward", d, True,
-         [_ptr(input), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(mask), _ptr(grad_output),
-          _ptr(grad_input), _ptr(grad_offset), _ptr(grad_mask), _ptr(grad_weight),
-          _ptr(grad_bias)], input)
+    with _capi.overwrite_grads():
+        _run("mdconv_modulated_deform_conv2d_backward", d, True,
+             [_ptr(input), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(mask), _ptr(grad_output),
+              _ptr(grad_input), _ptr(grad_offset), _ptr(grad_mask), _ptr(grad_weight),
+              _ptr(grad_bias)], input)
     return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias)
 
 

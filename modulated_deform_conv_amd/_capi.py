@@ -16,7 +16,7 @@ EXPORTS = (
     "mdconv_abi_version", "mdconv_last_error", "mdconv_out_size", "mdconv_workspace_bytes",
     "mdconv_set_path", "mdconv_last_path",
     "mdconv_profile_enable", "mdconv_profile_read", "mdconv_profile_reset",
-    "mdconv_stream_wait_weight_ready",
+    "mdconv_stream_wait_weight_ready", "mdconv_set_accumulate",
     "mdconv_deform_conv2d_forward", "mdconv_deform_conv2d_backward",
     "mdconv_modulated_deform_conv2d_forward", "mdconv_modulated_deform_conv2d_backward",
     "mdconv_deform_conv3d_forward", "mdconv_deform_conv3d_backward",
@@ -56,6 +56,8 @@ def lib():
         L.mdconv_profile_enable.restype = ctypes.c_int
         L.mdconv_profile_read.restype = ctypes.c_int
         L.mdconv_profile_reset.restype = None
+        L.mdconv_set_accumulate.restype = ctypes.c_int
+        L.mdconv_set_accumulate.argtypes = [ctypes.c_int]
         L.mdconv_stream_wait_weight_ready.restype = ctypes.c_int
         L.mdconv_stream_wait_weight_ready.argtypes = [ctypes.c_void_p]
         for name in EXPORTS[9:]:
@@ -82,6 +84,18 @@ def last_path():
 
 
 PROFILE_KERNELS = {0: "mfma_fwd_kernel", 1: "mfma_bwd_data_kernel", 2: "mfma_bwd_weight_kernel"}
+
+
+class overwrite_grads:
+    """Context manager: backward entry points called inside WRITE their gradients instead of adding
+    to them (include/mdconv.h: mdconv_set_accumulate), so the buffers may be torch.empty."""
+
+    def __enter__(self):
+        self._prev = lib().mdconv_set_accumulate(0)
+
+    def __exit__(self, *exc):
+        lib().mdconv_set_accumulate(self._prev)
+        return False
 
 
 def stream_wait_weight_ready(stream):

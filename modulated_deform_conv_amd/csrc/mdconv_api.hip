@@ -14,6 +14,7 @@ namespace mdconv {
 
 static thread_local char g_err[512] = "";
 static thread_local int g_last_path = 0;
+static thread_local int g_accumulate = 1;
 // "grad_weight / grad_bias are final" event of the last backward of this thread
 static thread_local hipEvent_t g_wready = nullptr;
 static thread_local int g_wready_dev = -1;
@@ -123,6 +124,7 @@ int fill_geom(const mdconv_desc *d, Geom *g) {
   g->Cdg = d->c_in / d->dgroups;
   g->with_bias = d->with_bias ? 1 : 0;
   g->modulated = d->modulated ? 1 : 0;
+  g->acc_data = g->acc_w = 1;
   // gating flavours of the four reference files
   const bool mdcn2d = d->ndim == 2 && d->modulated;
   const bool dcn2d = d->ndim == 2 && !d->modulated;
@@ -205,6 +207,7 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
     return rc;
   if (g.with_bias && (rc = require(t.grad_bias, "grad_bias"))) return rc;
   hipStream_t s = (hipStream_t)stream;
+  g.acc_data = g.acc_w = g_accumulate;
   const int path = current_path();
   const bool mfma_ok = mfma_supported(g, d->dtype, true);
   if (path == MDCONV_PATH_MFMA && !mfma_ok) {
@@ -217,6 +220,17 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
     return mfma_backward(g, d->dtype, t, ws, s);
   }
   g_last_path = MDCONV_PATH_DIRECT;
+  if (!g_accumulate) {
+    // the direct kernels scatter with atomics, so "overwrite" means: clear first
+    const size_t es = d->dtype == MDCONV_F64 ? 8 : (d->dtype == MDCONV_F16 ? 2 : 4);
+    const size_t n_off = (size_t)g.B * g.DG * g.nd * g.K * g.S_o, n_m = (size_t)g.B * g.DG * g.K * g.S_o;
+    if ((rc = zero_bytes(t.grad_input, (size_t)g.B * g.C * g.S_i * es, s)) ||
+        (rc = zero_bytes(t.grad_offset, n_off * es, s)) ||
+        (rc = zero_bytes(t.grad_weight, (size_t)g.O * g.Cg * g.K * es, s)))
+      return rc;
+    if (modulated && (rc = zero_bytes(t.grad_mask, n_m * es, s))) return rc;
+    if (g.with_bias && (rc = zero_bytes(t.grad_bias, (size_t)g.O * es, s))) return rc;
+  }
   if ((rc = direct_backward(g, d->dtype, t, s))) return rc;
   return record_weight_ready(s);
 }
@@ -266,6 +280,12 @@ size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward) {
   if (current_path() == MDCONV_PATH_DIRECT) return 0;
   if (!mfma_supported(g, d->dtype, backward != 0)) return 0;
   return mfma_workspace_bytes(g, d->dtype, backward != 0);
+}
+
+int mdconv_set_accumulate(int on) {
+  const int prev = g_accumulate;
+  g_accumulate = on ? 1 : 0;
+  return prev;
 }
 
 int mdconv_stream_wait_weight_ready(void *stream) {

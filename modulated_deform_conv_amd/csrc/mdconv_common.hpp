@@ -29,6 +29,10 @@ struct Geom {
   int range_gate;  // grad_offset only when -1 < p < size   (mdeformable_conv.cu:295)
   int with_bias;
   int modulated;
+  // backward: 1 = add to the caller's gradient buffers (reference semantics, the default),
+  // 0 = overwrite them (mdconv_set_accumulate); per-image gradients and weight gradients apart
+  // because batch chunks after the first must add to grad_weight / grad_bias in either mode
+  int acc_data, acc_w;
 };
 
 template <typename T> struct Acc { using type = float; };

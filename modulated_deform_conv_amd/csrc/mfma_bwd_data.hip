@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     }
     if (flush_ok && (slot == kTapGroup - 1 || tapp == g.K - 1 || last)) {
       __syncthreads();
-      // single owner of every (b, dg, tap, pix): plain accumulate (the C ABI accumulates into grads)
+      // single owner of every (b, dg, tap, pix): plain read-modify-write (or write, mdconv_set_accumulate)
       const int tap0 = tapp - slot;
       const int per_slot = g.DG * (ND + 1) * BNP;
       const int items = (slot + 1 - grp_lo) * per_slot;
@@ -389,8 +389,9 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
             sum += red[((sl * nblk + dgi * bpd + y) * (ND + 1) + a) * BNP + jj];
           const int b = n / g.S_o, pix = n - b * g.S_o, tp = tap0 + sl;
           const int64_t seg = (int64_t)b * g.DG + dgi;
-          if (a < ND) grad_offset[(seg * (ND * g.K) + ND * tp + a) * g.S_o + pix] += sum;
-          else grad_mask[(seg * g.K + tp) * g.S_o + pix] += sum;
+          float *dst = a < ND ? grad_offset + (seg * (ND * g.K) + ND * tp + a) * g.S_o + pix
+                              : grad_mask + (seg * g.K + tp) * g.S_o + pix;
+          *dst = g.acc_data ? *dst + sum : sum;
         }
       }
       __syncthreads();
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float 
           const float *src = tile + cc * (QT + 1) + qs;
 #pragma unroll
           for (int k = 0; k < 8; ++k)
-            if (q0 + qs + k < g.S_i) dst[k] += src[k];
+            if (q0 + qs + k < g.S_i) dst[k] = g.acc_data ? dst[k] + src[k] : src[k];
         }
       }
     }
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(256) void col2im_gather_grouped_kernel(
           const float *src = tile + cc * (QT + 1) + qs;
 #pragma unroll
           for (int k = 0; k < 8; ++k)
-            if (q0 + qs + k < g.S_i) dst[k] += src[k];
+            if (q0 + qs + k < g.S_i) dst[k] = g.acc_data ? dst[k] + src[k] : src[k];
         }
       }
     }

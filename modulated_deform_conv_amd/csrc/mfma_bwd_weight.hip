@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void reduce_weight_kernel(Geom g, BwdDims bd,
     float s = 0.f;
     for (int sp = 0; sp < bd.splits; ++sp)
       s += part[((size_t)(sp * g.K + tap) * bd.OgpB + o) * bd.Cp + c];
-    grad_weight[((int64_t)o * g.Cg + cl) * g.K + tap] += s;
+    float *dst = grad_weight + ((int64_t)o * g.Cg + cl) * g.K + tap;
+    *dst = g.acc_w ? *dst + s : s;
   }
 }
 
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void grad_bias_final_kernel(Geom g, int slices
   if (o >= g.O) return;
   float s = 0.f;
   for (int k = 0; k < slices; ++k) s += partial[(size_t)k * g.O + o];
-  grad_bias[o] += s;
+  grad_bias[o] = g.acc_w ? grad_bias[o] + s : s;
 }
 
 int grid_for(int64_t total) {

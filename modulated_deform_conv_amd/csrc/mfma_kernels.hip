@@ -43,7 +43,27 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(Geom g, PackDims pd,
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// scratch and gradients are cleared by kernels rather than hipMemsetAsync: memset nodes made HIP
+// graph replay fault (tools/graph_check.py), and a plain kernel sequence captures cleanly
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned *__restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void zero_halfwords_kernel(unsigned short *__restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
+}
+
 }  // namespace
+
+int zero_bytes(void *p, size_t bytes, hipStream_t s) {
+  if (bytes == 0 || p == nullptr) return MDCONV_OK;
+  const bool words = bytes % 4 == 0 && ((uintptr_t)p & 3) == 0;
+  const int64_t n = (int64_t)(words ? bytes / 4 : bytes / 2);
+  const int64_t blocks = (n + 255) / 256;
+  const dim3 grid((unsigned)(blocks > 8192 ? 8192 : blocks));
+  if (words) hipLaunchKernelGGL(zero_words_kernel, grid, dim3(256), 0, s, (unsigned *)p, n);
+  else hipLaunchKernelGGL(zero_halfwords_kernel, grid, dim3(256), 0, s, (unsigned short *)p, n);
+  return check_launch("zero");
+}
 
 void profile_mark(int which, bool begin, hipStream_t stream) {
   if (!g_prof_on || which < 0 || which > 2) return;
@@ -220,19 +240,6 @@ int narrow(const float *src, void *dst, int64_t n, bool accum, hipStream_t s) {
     hipLaunchKernelGGL(narrow_kernel<false>, dim3(nblocks(n)), dim3(256), 0, s, src, (__half *)dst, n);
   return check_launch("narrow");
 }
-// cleared by a kernel rather than hipMemsetAsync: memset nodes made HIP graph replay fault
-// (tools/graph_check.py), and a plain kernel sequence captures cleanly
-__global__ __launch_bounds__(256) void zero_words_kernel(unsigned *__restrict__ p, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0u;
-}
-int zero(void *p, size_t bytes, hipStream_t s) {   // bytes is a multiple of 4 (fp32 buffers)
-  if (bytes == 0) return MDCONV_OK;
-  const int64_t n = (int64_t)(bytes / 4);
-  const int64_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, s,
-                     (unsigned *)p, n);
-  return check_launch("zero");
-}
 
 // fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`).
 // Order on the caller's stream:
@@ -352,12 +359,15 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
   int rc;
   if (p.half_io) {
     if ((rc = widen(t.weight, (float *)(base + p.off_w), n_w, stream))) return rc;
-    if ((rc = zero(base + p.off_gw, n_w * 4, stream)) || (rc = zero(base + p.off_gb, (size_t)g.O * 4, stream)))
-      return rc;
   }
   for (int b0 = 0; b0 < g.B; b0 += p.Bc) {
     const int bc = g.B - b0 < p.Bc ? g.B - b0 : p.Bc;
-    const Geom gc = chunk_geom(g, bc);
+    Geom gc = chunk_geom(g, bc);
+    // grad_weight / grad_bias: chunks after the first always add; the fp32 temporaries of the fp16
+    // path are fresh memory, so every kernel overwrites them (no zero fills) and the caller's mode
+    // is applied when they are narrowed back
+    gc.acc_w = (b0 > 0) ? 1 : (p.half_io ? 0 : g.acc_w);
+    gc.acc_data = p.half_io ? 0 : g.acc_data;
     const size_t o_x = (size_t)b0 * g.C * g.S_i, o_off = (size_t)b0 * nc_off * g.S_o;
     const size_t o_m = (size_t)b0 * nc_m * g.S_o, o_go = (size_t)b0 * g.O * g.S_o;
     Tensors tc = t;
@@ -368,19 +378,16 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
       if ((rc = widen((const char *)t.offset + o_off * es, (float *)(base + p.off_off), n_off, stream))) return rc;
       if (t.mask && (rc = widen((const char *)t.mask + o_m * es, (float *)(base + p.off_m), n_m, stream))) return rc;
       if ((rc = widen((const char *)t.grad_output + o_go * es, (float *)(base + p.off_go), n_go, stream))) return rc;
-      if ((rc = zero(base + p.off_gi, n_x * 4, stream)) || (rc = zero(base + p.off_goff, n_off * 4, stream)) ||
-          (rc = zero(base + p.off_gm, n_m * 4, stream)))
-        return rc;
       tc.input = base + p.off_x; tc.offset = base + p.off_off; tc.mask = t.mask ? base + p.off_m : nullptr;
       tc.weight = base + p.off_w; tc.grad_output = base + p.off_go;
       tc.grad_input = base + p.off_gi; tc.grad_offset = base + p.off_goff;
       tc.grad_mask = t.grad_mask ? base + p.off_gm : nullptr;
       tc.grad_weight = base + p.off_gw; tc.grad_bias = base + p.off_gb;
       if ((rc = backward_chunk_f32(gc, tc, base, stream, false))) return rc;
-      if ((rc = narrow((const float *)tc.grad_input, (char *)t.grad_input + o_x * es, n_x, true, stream))) return rc;
-      if ((rc = narrow((const float *)tc.grad_offset, (char *)t.grad_offset + o_off * es, n_off, true, stream))) return rc;
+      if ((rc = narrow((const float *)tc.grad_input, (char *)t.grad_input + o_x * es, n_x, g.acc_data != 0, stream))) return rc;
+      if ((rc = narrow((const float *)tc.grad_offset, (char *)t.grad_offset + o_off * es, n_off, g.acc_data != 0, stream))) return rc;
       if (t.grad_mask &&
-          (rc = narrow((const float *)tc.grad_mask, (char *)t.grad_mask + o_m * es, n_m, true, stream)))
+          (rc = narrow((const float *)tc.grad_mask, (char *)t.grad_mask + o_m * es, n_m, g.acc_data != 0, stream)))
         return rc;
     } else {
       tc.input = (const char *)t.input + o_x * es;
@@ -394,8 +401,8 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
     }
   }
   if (p.half_io) {
-    if ((rc = narrow((const float *)(base + p.off_gw), t.grad_weight, n_w, true, stream))) return rc;
-    if (g.with_bias && (rc = narrow((const float *)(base + p.off_gb), t.grad_bias, g.O, true, stream))) return rc;
+    if ((rc = narrow((const float *)(base + p.off_gw), t.grad_weight, n_w, g.acc_w != 0, stream))) return rc;
+    if (g.with_bias && (rc = narrow((const float *)(base + p.off_gb), t.grad_bias, g.O, g.acc_w != 0, stream))) return rc;
     if ((rc = record_weight_ready(stream))) return rc;
   }
   return MDCONV_OK;

@@ -13,6 +13,9 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
 // (include/mdconv.h: mdconv_stream_wait_weight_ready)
 int record_weight_ready(hipStream_t stream);
 
+// clears `bytes` (a multiple of 2) of device memory with a kernel (graph-capture friendly)
+int zero_bytes(void *p, size_t bytes, hipStream_t stream);
+
 // benchmark hooks (include/mdconv.h: mdconv_profile_*)
 void profile_mark(int which, bool begin, hipStream_t stream);
 

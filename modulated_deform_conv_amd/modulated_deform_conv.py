@@ -17,7 +17,7 @@ from torch.amp import custom_bwd, custom_fwd
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair, _triple
 
-from . import MDCONV_CUDA
+from . import MDCONV_CUDA, _capi
 
 __all__ = [
     "DeformConv2dFunction", "ModulatedDeformConv2dFunction", "DeformConv3dFunction",
@@ -95,16 +95,19 @@ def _make_function(nd, modulated, name):
             grad_input, grad_offset, grad_mask, grad_weight, grad_bias = bwd(
                 input, weight, bias, offset, mask, grad_output, *geo)
         else:
-            grad_input, grad_offset = torch.zeros_like(input), torch.zeros_like(offset)
-            grad_weight, grad_bias = torch.zeros_like(weight), torch.zeros_like(bias)
-            if modulated:
-                grad_mask = torch.zeros_like(mask)
-                bwd(input, weight, bias, offset, mask, grad_input, grad_weight, grad_bias,
-                    grad_offset, grad_mask, grad_output, *geo)
-            else:
-                grad_mask = None
-                bwd(input, weight, bias, offset, grad_input, grad_weight, grad_bias, grad_offset,
-                    grad_output, *geo)
+            # the reference wrapper zero-fills and the entry points add (:53-56); here the buffers
+            # are fresh, so the library is asked to write them instead (mdconv_set_accumulate)
+            grad_input, grad_offset = torch.empty_like(input), torch.empty_like(offset)
+            grad_weight, grad_bias = torch.empty_like(weight), torch.empty_like(bias)
+            with _capi.overwrite_grads():
+                if modulated:
+                    grad_mask = torch.empty_like(mask)
+                    bwd(input, weight, bias, offset, mask, grad_input, grad_weight, grad_bias,
+                        grad_offset, grad_mask, grad_output, *geo)
+                else:
+                    grad_mask = None
+                    bwd(input, weight, bias, offset, grad_input, grad_weight, grad_bias, grad_offset,
+                        grad_output, *geo)
         if not ctx.with_bias:
             grad_bias = None
         head = (grad_input, grad_offset, grad_mask) if modulated else (grad_input, grad_offset)

@@ -24,7 +24,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
-from . import MDCONV_CUDA
+from . import MDCONV_CUDA, _capi
 
 __all__ = ["deform_conv", "deform_conv_backward", "output_size"]
 
@@ -150,14 +150,15 @@ def deform_conv_backward(grad_output: torch.Tensor, input: torch.Tensor, offset:
     if mask is not None and nd == 2:
         gi, goff, gm, gw, gb = fn(input, weight, b, offset, mask, grad_output, *geo)
         return gi, goff, gm, gw, gb
-    gi, goff = torch.zeros_like(input), torch.zeros_like(offset)
-    gw, gb = torch.zeros_like(weight), torch.zeros_like(b)
-    if mask is not None:
-        gm = torch.zeros_like(mask)
-        fn(input, weight, b, offset, mask, gi, gw, gb, goff, gm, grad_output, *geo)
-    else:
-        gm = input.new_empty(0)
-        fn(input, weight, b, offset, gi, gw, gb, goff, grad_output, *geo)
+    gi, goff = torch.empty_like(input), torch.empty_like(offset)
+    gw, gb = torch.empty_like(weight), torch.empty_like(b)
+    with _capi.overwrite_grads():   # fresh buffers: written, not added to
+        if mask is not None:
+            gm = torch.empty_like(mask)
+            fn(input, weight, b, offset, mask, gi, gw, gb, goff, gm, grad_output, *geo)
+        else:
+            gm = input.new_empty(0)
+            fn(input, weight, b, offset, gi, gw, gb, goff, grad_output, *geo)
     return gi, goff, gm, gw, gb
 
 

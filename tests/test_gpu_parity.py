@@ -134,3 +134,49 @@ print("CHUNK_OK")
     env = dict(os.environ, MDCONV_CHUNK_LIMIT_BYTES=str(4 * 1024 * 1024))   # 2 or 1 images per chunk at these sizes
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "CHUNK_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name, dtype, path", [
+    ("dcn2d_s2_g2_dg2", torch.float32, "direct"),
+    ("mdcn3d_dil2_dg2", torch.float16, "direct"),
+    ("cfg2s_dcn2d_c64_28x28_b4", torch.float32, "auto"),
+    ("cfg4s_dcn3d_c16_12cubed_b2", torch.float32, "auto"),
+    ("mfma_mdcn3d_g2_dg2_c128_o32", torch.float32, "auto"),
+    ("mfma_mdcn3d_g2_dg2_c128_o32", torch.float16, "auto"),
+    ("mfma_dcn2d_c512_o32_7x5", torch.float32, "auto"),
+])
+def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
+    """mdconv_set_accumulate(0): the caller-allocated backward entry points must WRITE every element
+    of every gradient (buffers pre-filled with NaN) and give the accumulate-into-zeros result."""
+    from modulated_deform_conv_amd import MDCONV_CUDA as M, _capi
+    from tests.cases import CASE_BY_NAME, ndim
+    from tests.util import tup
+    case = CASE_BY_NAME[name]
+    t = make_inputs(case, dtype=dtype, device="cuda")
+    _, want, _ = run_product(case, t, path)          # accumulate into zeros (reference semantics)
+    nd = ndim(case)
+    k, s, p, d = (tup(case[x], nd) for x in ("k", "stride", "padding", "dilation"))
+    geo = k + s + p + d + (case["groups"], case["dgroups"], case["in_step"], case["bias"])
+    x, w, off, m, go = t["input"], t["weight"], t["offset"], t["mask"], t["grad_output"]
+    b = t["bias"] if case["bias"] else x.new_empty(0)
+    nan = lambda ref: torch.full_like(ref, float("nan"))
+    gi, gw, gb, goff = nan(x), nan(w), nan(b), nan(off)
+    gm = nan(m) if m is not None else None
+    fn = getattr(M, "%sdeform_conv%dd_backward_cuda" % ("modulated_" if m is not None else "", nd))
+    prev = _capi.set_path(path)
+    try:
+        with _capi.overwrite_grads():
+            if m is None:
+                fn(x, w, b, off, gi, gw, gb, goff, go, *geo)
+            elif nd == 3:
+                fn(x, w, b, off, m, gi, gw, gb, goff, gm, go, *geo)
+    finally:
+        _capi.set_path(prev)
+    got = {"grad_input": gi, "grad_weight": gw, "grad_offset": goff, "grad_mask": gm,
+           "grad_bias": gb if case["bias"] else None}
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    for key, g in got.items():
+        if g is None or want[key] is None:
+            continue
+        assert torch.isfinite(g).all(), key
+        assert_close(key, g, want[key], tol)
