@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
-    float *__restrict__ ga, int *__restrict__ cnt, int ntiles, int n_full, int n_tail) {
+    float *__restrict__ ga, float *__restrict__ bias_part, int *__restrict__ cnt, int ntiles,
+    int n_full, int n_tail) {
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -244,6 +245,15 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       if (o < Opad) v = make_float4(src[0], src[gpitch], src[2 * gpitch], src[3 * gpitch]);
       reinterpret_cast<float4 *>(ga)[((int64_t)nchunk * bd.mblks + mblk) * 128 + q * 64 + ln] = v;
     }
+    // ... and the tile's share of grad_bias: bias_part[tile][o] = sum over the tile's pixels
+    // (dead pixels are 0 in LDS); summed over tiles in a fixed order by grad_bias_final_kernel
+    if (bias_part != nullptr)
+      for (int o = tid; o < g.O; o += 256) {
+        float sacc = 0.f;
+#pragma unroll 8
+        for (int px = 0; px < BNP; ++px) sacc += Gs[px * gpitch + o];
+        bias_part[(int64_t)tile * g.O + o] = sacc;
+      }
   };
 
   // sampling state of the tap being drained; before the first drain every gather / store goes
@@ -801,7 +811,7 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
 }
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
-                      float *gcol, float *ga, int *cnt, hipStream_t stream) {
+                      float *gcol, float *ga, float *bias_part, int *cnt, hipStream_t stream) {
   // cnt: per-(image, deformable group, input pixel) counters (zeroed by csr_zero_f32), counted
   // by GEMM-1 (CSR pass 1)
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
@@ -824,7 +834,8 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
-                       (float *)t.grad_offset, (float *)t.grad_mask, ga, cnt, ntiles, n_full, n_tail); \
+                       (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, ntiles, n_full,    \
+                       n_tail);                                                                 \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \

@@ -267,31 +267,35 @@ __global__ __launch_bounds__(256) void reduce_weight_kernel(Geom g, BwdDims bd,
   }
 }
 
-// grad_bias[o] += sum_{b, pix} grad_out[b][o][pix]   (mdeformable_conv.cu:440-444), in two
-// deterministic stages (no floating-point atomics: the result is bit-identical from run to run):
-// grid (O, slices) partial sums over image slices, then one ordered sum per output channel.
-__global__ __launch_bounds__(256) void grad_bias_partial_kernel(Geom g, const float *__restrict__ gout,
-                                                                float *__restrict__ partial) {
-  __shared__ float red[4];
-  const int o = blockIdx.x;
+// grad_bias[o] += sum_{b, pix} grad_out[b][o][pix]   (mdeformable_conv.cu:440-444): GEMM-1 leaves one
+// partial sum per (pixel tile, o) (mfma_bwd_data.hip, emit_ga); they are added here in a fixed
+// order (two small stages) -- no floating-point atomics, the result is bit-identical from run to
+// run.
+constexpr int kBiasSlices = 32;
+// stage 1: grid (O / 64, kBiasSlices); thread = (o, quarter): tiles k = slice * 4 + quarter (mod 128)
+__global__ __launch_bounds__(256) void grad_bias_stage1_kernel(Geom g, int tiles,
+                                                               const float *__restrict__ partial,
+                                                               float *__restrict__ stage) {
+  __shared__ float red[4][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int quarter = threadIdx.x >> 6;
   float s = 0.f;
-  for (int b = blockIdx.y; b < g.B; b += gridDim.y) {
-    const float *row = gout + (int64_t)(b * g.O + o) * g.S_o;
-    for (int i = threadIdx.x; i < g.S_o; i += 256) s += row[i];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  if (o < g.O)
+    for (int k = blockIdx.y * 4 + quarter; k < tiles; k += 4 * kBiasSlices) s += partial[(size_t)k * g.O + o];
+  red[quarter][threadIdx.x & 63] = s;
   __syncthreads();
-  if (threadIdx.x == 0) partial[(size_t)blockIdx.y * g.O + o] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (quarter == 0 && o < g.O)
+    stage[(size_t)blockIdx.y * g.O + o] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ __launch_bounds__(256) void grad_bias_final_kernel(Geom g, int slices,
-                                                              const float *__restrict__ partial,
+// stage 2: one ordered sum of the kBiasSlices stage values per output channel
+__global__ __launch_bounds__(256) void grad_bias_final_kernel(Geom g, const float *__restrict__ stage,
                                                               float *__restrict__ grad_bias) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= g.O) return;
   float s = 0.f;
-  for (int k = 0; k < slices; ++k) s += partial[(size_t)k * g.O + o];
+#pragma unroll
+  for (int k = 0; k < kBiasSlices; ++k) s += stage[(size_t)k * g.O + o];
   grad_bias[o] = g.acc_w ? grad_bias[o] + s : s;
 }
 
@@ -316,7 +320,7 @@ int build_tap_table_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int 
 }
 
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
-                        const int *table, float *part, hipStream_t stream) {
+                        const int *table, float *part, const float *bias_part, hipStream_t stream) {
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
   const bool padn = bd.Np != g.N;
   profile_mark(2, true, stream);
@@ -338,13 +342,12 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
                      stream, g, bd, part, (float *)t.grad_weight);
   if ((rc = check_launch("reduce_weight"))) return rc;
   if (g.with_bias) {
-    // the split-K partials are consumed by now: `part` doubles as scratch for the bias partials
-    const int slices = g.B < 16 ? g.B : 16;
-    hipLaunchKernelGGL(grad_bias_partial_kernel, dim3(g.O, slices), dim3(256), 0, stream, g,
-                       (const float *)t.grad_output, part);
-    if ((rc = check_launch("grad_bias_partial"))) return rc;
-    hipLaunchKernelGGL(grad_bias_final_kernel, dim3((g.O + 255) / 256), dim3(256), 0, stream, g,
-                       slices, part, (float *)t.grad_bias);
+    // the split-K partials are consumed by now: `part` doubles as scratch for the stage values
+    hipLaunchKernelGGL(grad_bias_stage1_kernel, dim3((g.O + 63) / 64, kBiasSlices), dim3(256), 0,
+                       stream, g, bd.bias_tiles, bias_part, part);
+    if ((rc = check_launch("grad_bias_stage1"))) return rc;
+    hipLaunchKernelGGL(grad_bias_final_kernel, dim3((g.O + 255) / 256), dim3(256), 0, stream, g, part,
+                       (float *)t.grad_bias);
     rc = check_launch("grad_bias_final");
   }
   return rc;

@@ -124,6 +124,8 @@ BwdDims bwd_dims(const Geom &g) {
   bd.off_cnt = off;  off += align_up((size_t)g.B * g.DG * g.S_i * sizeof(int));
   bd.off_rowptr = off; off += align_up((size_t)g.B * g.DG * (g.S_i + 1) * sizeof(int));
   bd.off_entries = off; off += align_up((size_t)g.B * g.DG * g.K * g.S_o * nc * 8);
+  bd.bias_tiles = (g.N + 32 * (4 / bd.waves_c) - 1) / (32 * (4 / bd.waves_c));
+  bd.off_bias = off; off += align_up((size_t)bd.bias_tiles * g.O * sizeof(float));
   bd.off_end = off;
   return bd;
 }
@@ -267,10 +269,11 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
   if ((rc = csr_zero_f32(g, cnt, stream))) return rc;
   profile_mark(1, true, stream);
-  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, cnt, stream);
+  float *bias_part = g.with_bias ? (float *)(base + bd.off_bias) : nullptr;
+  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, stream);
   profile_mark(1, false, stream);
   if (rc) return rc;
-  if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, stream))) return rc;
+  if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, stream))) return rc;
   if (weights_final && (rc = record_weight_ready(stream))) return rc;
   if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, stream))) return rc;
   return col2im_f32(g, t, gcol, rowptr, entries, stream);

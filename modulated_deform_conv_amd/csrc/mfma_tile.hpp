@@ -78,7 +78,9 @@ struct BwdDims {
   int ochunks;          // C_out rounded up to 32, /16 (even): K chunks of GEMM-1
   int waves_c, cblks_q; // GEMM-1: waves along channels (4/2/1), 32-channel blocks of wq
   // workspace byte offsets
-  size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_end;
+  int bias_tiles;       // pixel tiles of GEMM-1 = rows of the grad_bias partial sums
+  size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
+      off_end;
 };
 BwdDims bwd_dims(const Geom &g);
 
@@ -97,11 +99,11 @@ int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const 
 int build_tap_table_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *table,
                         hipStream_t stream);
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
-                        const int *table, float *part, hipStream_t stream);
+                        const int *table, float *part, const float *bias_part, hipStream_t stream);
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
-                      float *gcol, float *ga, int *cnt, hipStream_t stream);
+                      float *gcol, float *ga, float *bias_part, int *cnt, hipStream_t stream);
 int csr_zero_f32(const Geom &g, int *cnt, hipStream_t stream);
 int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
                   hipStream_t stream);
