@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
-    float *__restrict__ ga, float *__restrict__ bias_part, int *__restrict__ cnt, int ntiles,
-    int n_full, int n_tail) {
+    float *__restrict__ ga, float *__restrict__ bias_part, int *__restrict__ cnt,
+    int *__restrict__ table, int ntiles, int n_full, int n_tail) {
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -297,6 +297,26 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     int pidx[NP];
     float px[NP], py[NP];
     make_pairs<ND, float>(g, tc, 1.f, pidx, px, py);
+    if (count && kh == 0) {
+      // ... and writes the tap-table entry GEMM-2 reads for (dgp, tapp, pixel): byte offsets of
+      // the corner pairs (image base folded in) + the 2^ND weights with the mask folded in
+      // (layout: mfma_bwd_weight.hip); pixels of the padded tail get an all-zero entry
+      const int n = pp.n0 + wp * 32 + lane;
+      if (n < bd.Np) {
+        int *e = table + ((int64_t)(dgp * g.K + tapp) * bd.Np + n) * (2 * NC);
+        int ev[2 * NC];
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+          ev[pi] = pp.live ? (pp.b * g.C * g.S_i + pidx[pi]) * 4 : 0;
+          ev[NP + pi] = 0;
+          ev[NC + 2 * pi] = pp.live ? __float_as_int(px[pi] * m_n) : 0;
+          ev[NC + 2 * pi + 1] = pp.live ? __float_as_int(py[pi] * m_n) : 0;
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 2 * NC; q4 += 4)
+          *reinterpret_cast<int4 *>(e + q4) = make_int4(ev[q4], ev[q4 + 1], ev[q4 + 2], ev[q4 + 3]);
+      }
+    }
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
       voff[pi] = (pp.b * g.C * g.S_i + pidx[pi] + 4 * kh * g.S_i) * 4;
@@ -811,7 +831,8 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
 }
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
-                      float *gcol, float *ga, float *bias_part, int *cnt, hipStream_t stream) {
+                      float *gcol, float *ga, float *bias_part, int *cnt, int *table,
+                      hipStream_t stream) {
   // cnt: per-(image, deformable group, input pixel) counters (zeroed by csr_zero_f32), counted
   // by GEMM-1 (CSR pass 1)
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
@@ -834,8 +855,8 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
-                       (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, ntiles, n_full,    \
-                       n_tail);                                                                 \
+                       (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, table, ntiles,    \
+                       n_full, n_tail);                                                         \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \

@@ -32,48 +32,8 @@ namespace {
 // weights (validity, backward load gating and the mask folded in).
 // Entry = kTabWords(ND) words: [NP offsets | pad][NC weights]  (8 words in 2-D, 16 in 3-D).
 // ---------------------------------------------------------------------------------------------
-template <int ND, bool MOD>
-__global__ __launch_bounds__(256) void tap_table_kernel(Geom g, int Np, const float *__restrict__ offset,
-                                                        const float *__restrict__ mask,
-                                                        int *__restrict__ table) {
-  constexpr int NC = 1 << ND, NP = NC / 2, TW = 2 * NC;   // TW words per entry
-  const int64_t total = (int64_t)g.DG * g.K * Np;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int n = (int)(i % Np);
-    const int tap = (int)((i / Np) % g.K);
-    const int dg = (int)(i / Np / g.K);
-    int vo[NP];
-    float wx[NP], wy[NP];
-    if (n < g.N) {
-      const int b = n / g.S_o, pix = n - b * g.S_o;
-      int oc[ND], tcd[ND];
-      out_coords<ND>(g, pix, oc);
-      tap_coords<ND>(g, tap, tcd);
-      float delta[ND];
-      const int64_t ob = ((int64_t)(b * g.DG + dg) * (ND * g.K) + ND * tap) * g.S_o + pix;
-#pragma unroll
-      for (int a = 0; a < ND; ++a) delta[a] = offset[ob + (int64_t)a * g.S_o];
-      TapCoef<ND, float> tc;
-      make_tap<ND, float>(g, oc, tcd, delta, true, tc);
-      const float m = MOD ? mask[((int64_t)(b * g.DG + dg) * g.K + tap) * g.S_o + pix] : 1.f;
-      make_pairs<ND, float>(g, tc, m, vo, wx, wy);
-#pragma unroll
-      for (int pi = 0; pi < NP; ++pi) vo[pi] = (b * g.C * g.S_i + vo[pi]) * 4;
-    } else {
-#pragma unroll
-      for (int pi = 0; pi < NP; ++pi) { vo[pi] = 0; wx[pi] = 0.f; wy[pi] = 0.f; }
-    }
-    int *e = table + i * TW;
-#pragma unroll
-    for (int pi = 0; pi < NP; ++pi) {
-      e[pi] = vo[pi];
-      e[NP + pi] = 0;
-      e[NC + 2 * pi] = __float_as_int(wx[pi]);
-      e[NC + 2 * pi + 1] = __float_as_int(wy[pi]);
-    }
-  }
-}
-
+// (The table is written by GEMM-1, mfma_bwd_data.hip `new_tap_state`, which computes the same
+// sampling state anyway.)
 // ---------------------------------------------------------------------------------------------
 // the GEMM
 // ---------------------------------------------------------------------------------------------
@@ -305,19 +265,6 @@ int grid_for(int64_t total) {
 }
 
 }  // namespace
-
-int build_tap_table_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *table,
-                        hipStream_t stream) {
-  const int64_t total = (int64_t)g.DG * g.K * bd.Np;
-  const dim3 grid(grid_for(total));
-#define LAUNCH_TT(ND, MOD)                                                                     \
-  hipLaunchKernelGGL((tap_table_kernel<ND, MOD>), grid, dim3(256), 0, stream, g, bd.Np,          \
-                     (const float *)t.offset, (const float *)t.mask, table)
-  if (g.nd == 2) { if (g.modulated) LAUNCH_TT(2, true); else LAUNCH_TT(2, false); }
-  else { if (g.modulated) LAUNCH_TT(3, true); else LAUNCH_TT(3, false); }
-#undef LAUNCH_TT
-  return check_launch("tap_table");
-}
 
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, hipStream_t stream) {

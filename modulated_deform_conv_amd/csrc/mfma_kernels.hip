@@ -245,8 +245,9 @@ int narrow(const float *src, void *dst, int64_t n, bool accum, hipStream_t s) {
 
 // fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`).
 // Order on the caller's stream:
-//   tap table, pack_wq, zero counters
-//   -> GEMM-1 (+ coordinate gradients, grad_col, packed grad_out, CSR counting pass)
+//   pack_wq, zero counters
+//   -> GEMM-1 (+ coordinate gradients, grad_col, and for GEMM-2: packed grad_out, tap table,
+//      grad_bias partials; CSR counting pass)
 //   -> GEMM-2, split-K reduce, grad_bias -> [weights-ready event] -> CSR scan + fill -> col2im
 // grad_weight / grad_bias are produced BEFORE the grad_input gather so that a data-parallel
 // all-reduce of them can run under the gather (mdconv_stream_wait_weight_ready).
@@ -265,12 +266,11 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   int *cnt = (int *)(base + bd.off_cnt), *rowptr = (int *)(base + bd.off_rowptr);
   void *entries = base + bd.off_entries;
   int rc;
-  if ((rc = build_tap_table_f32(g, bd, t, table, stream))) return rc;
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
   if ((rc = csr_zero_f32(g, cnt, stream))) return rc;
   profile_mark(1, true, stream);
   float *bias_part = g.with_bias ? (float *)(base + bd.off_bias) : nullptr;
-  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, stream);
+  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, stream);
   profile_mark(1, false, stream);
   if (rc) return rc;
   if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, stream))) return rc;

@@ -96,14 +96,13 @@ int pack_weights_f32(const Geom &g, const PackDims &pd, const float *weight, flo
                      hipStream_t stream);
 int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
                      hipStream_t stream);
-int build_tap_table_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *table,
-                        hipStream_t stream);
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, hipStream_t stream);
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
-                      float *gcol, float *ga, float *bias_part, int *cnt, hipStream_t stream);
+                      float *gcol, float *ga, float *bias_part, int *cnt, int *table,
+                      hipStream_t stream);
 int csr_zero_f32(const Geom &g, int *cnt, hipStream_t stream);
 int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
                   hipStream_t stream);
