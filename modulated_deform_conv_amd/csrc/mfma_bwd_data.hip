@@ -450,9 +450,9 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   };
   // four chunks t .. t+3 of (tap, pass); A runs three chunks ahead (into the next iteration).
   // (Fetching the B fragments a chunk ahead as well was measured slower: 1.24 -> 1.30 ms.)
-  auto quad = [&](int t, bool fresh) {
+  auto quad_head = [&](int t) { load_a(ra3, a_off(t + 3)); };
+  auto quad_tail = [&](int t, bool fresh) {
     const float *bq = Bb + b_cur;
-    load_a(ra3, a_off(t + 3));
     __builtin_amdgcn_sched_barrier(0);
     mma(ra0, bq + t * 16, fresh);
     load_a(ra0, a_off(t + 4));
@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     __builtin_amdgcn_sched_barrier(0);
     mma(ra3, bq + (t + 3) * 16, false);
   };
+  auto quad = [&](int t, bool fresh) { quad_head(t); quad_tail(t, fresh); };
 
   int tile_c = -1;   // tile whose grad_out is in LDS
   int tapp = 0, passp = 0;   // (tap, pass) of the parked accumulators
@@ -515,12 +516,16 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
 #pragma unroll
     for (int q = 0; q < NBATCH; ++q) {
       float2 v[RB][NP];
+      // straight-line path: the A fragment of chunk t+3 is requested BEFORE the gathers, so only
+      // the fragment of chunk t+4 (needed four chunks later) queues behind them
+      if (QPQ > 0) quad_head(q * QPQ * 4);
       gather(q, cbase_p, v);
       asm volatile("" ::: "memory");   // IR-level fence: keep batch q's gathers here
       __builtin_amdgcn_sched_barrier(0);
       if (QPQ > 0) {
+        quad_tail(q * QPQ * 4, q == 0);
 #pragma unroll
-        for (int jq = 0; jq < QPQ; ++jq) quad((q * QPQ + jq) * 4, q == 0 && jq == 0);
+        for (int jq = 1; jq < QPQ; ++jq) quad((q * QPQ + jq) * 4, false);
       } else {
         for (int qd = nq * q / NBATCH; qd < nq * (q + 1) / NBATCH; ++qd) quad(qd * 4, false);
       }
