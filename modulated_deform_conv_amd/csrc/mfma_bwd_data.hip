@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
 // short workgroups.  (With one workgroup per tile, cfg2's 3136 tiles over 512 slots left the
 // seventh round 1/8 full: ~12 % of the kernel.  A fully persistent grid -- one long unit range
 // per slot -- was measured 25 % SLOWER: every workgroup then runs in phase with every other and
-// they all hit the same few L2 channels at the same time.)  A tile split between workgroups
+// they all hit the same few L2 channels at the same time; 2 / 3 / 6 tiles per workgroup: 1.28 /
+// 1.31 / 1.40 ms vs 1.26 for one; 5 / 3 / 1 taps per workgroup: 1.44 / 1.46 / 2.06 ms.)  A tile
+// split between workgroups
 // needs no atomics: grad_col, grad_offset and grad_mask are all per-tap outputs.
 //
 // The grad_out tile ([C_out] x BNP pixels, 32 KB at cfg2) does not depend on the tap, so it is
