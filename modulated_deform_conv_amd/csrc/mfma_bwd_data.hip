@@ -290,15 +290,20 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     TapCoef<ND, float> tc;
     make_tap<ND, float>(g, pp.oc, tcd, delta_n, true, tc);
     mg = (!g.range_gate || tc.inside) ? m_n : 0.f;
-    if (count && kh == 0 && pp.live) {
-      int *cseg = cnt + ((int64_t)pp.b * g.DG + dgp) * g.S_i;
-#pragma unroll
-      for (int ci = 0; ci < NC; ++ci)
-        if (corner_weight_atom<ND, float>(tc, ci) != 0.f) atomicAdd(cseg + corner_index<ND, float>(tc, ci), 1);
-    }
     int pidx[NP];
     float px[NP], py[NP];
     make_pairs<ND, float>(g, tc, 1.f, pidx, px, py);
+    if (count && kh == 0 && pp.live) {
+      // scatter targets of this sample = its corner PAIRS with a non-zero scatter weight, keyed by
+      // the pair's first element (the "anchor"; the col2im gather walks anchors, see below)
+      int aidx[NP];
+      float ax[NP], ay[NP];
+      make_pairs_f<ND, float>(g, tc, tc.wl, tc.wha, 1.f, aidx, ax, ay);
+      int *cseg = cnt + ((int64_t)pp.b * g.DG + dgp) * g.S_i;
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi)
+        if (ax[pi] != 0.f || ay[pi] != 0.f) atomicAdd(cseg + aidx[pi], 1);
+    }
     if (count && kh == 0) {
       // ... and writes the tap-table entry GEMM-2 reads for (dgp, tapp, pixel): byte offsets of
       // the corner pairs (image base folded in) + the 2^ND weights with the mask folded in
@@ -575,41 +580,44 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
 // ---------------------------------------------------------------------------------------------
 // 2. inverse scatter map (CSR keyed by (image, deformable group, input pixel))
 // ---------------------------------------------------------------------------------------------
-template <int ND, bool MOD, bool FILL>
-__global__ __launch_bounds__(256) void csr_pass_kernel(Geom g, const float *__restrict__ offset,
+// Fill pass of the inverted scatter map.  An ENTRY belongs to the anchor (first element) of a
+// corner pair of one sample and carries both scatter weights:
+//   (tap * S_o + output pixel, weight on the anchor, weight on anchor + 1, 0)
+// -- half as many entries, integer atomics and grad_col row reads as one entry per corner.
+template <int ND, bool MOD>
+__global__ __launch_bounds__(256) void csr_fill_kernel(Geom g, const float *__restrict__ offset,
                                                        const float *__restrict__ mask,
-                                                       int *__restrict__ cnt_or_cursor,
+                                                       int *__restrict__ cursor,
                                                        const int *__restrict__ rowptr,
-                                                       int2 *__restrict__ entries) {
-  constexpr int NC = 1 << ND;
+                                                       int4 *__restrict__ entries) {
+  constexpr int NP = 1 << (ND - 1);
   // a segment is one (image, deformable group): offset / mask are laid out [b][dg][...]
   const int64_t total = (int64_t)g.B * g.DG * g.K * g.S_o;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int pix = (int)(i % g.S_o);
     const int tap = (int)((i / g.S_o) % g.K);
-    const int b = (int)(i / g.S_o / g.K);   // segment index b * DG + dg
+    const int seg = (int)(i / g.S_o / g.K);   // b * DG + dg
     int oc[ND], tcd[ND];
     out_coords<ND>(g, pix, oc);
     tap_coords<ND>(g, tap, tcd);
     float delta[ND];
-    const int64_t ob = ((int64_t)b * (ND * g.K) + ND * tap) * g.S_o + pix;
+    const int64_t ob = ((int64_t)seg * (ND * g.K) + ND * tap) * g.S_o + pix;
 #pragma unroll
     for (int a = 0; a < ND; ++a) delta[a] = offset[ob + (int64_t)a * g.S_o];
     TapCoef<ND, float> tc;
     make_tap<ND, float>(g, oc, tcd, delta, true, tc);
-    const float m = MOD ? mask[((int64_t)b * g.K + tap) * g.S_o + pix] : 1.f;
+    const float m = MOD ? mask[((int64_t)seg * g.K + tap) * g.S_o + pix] : 1.f;
+    int aidx[NP];
+    float ax[NP], ay[NP], ux[NP], uy[NP];
+    make_pairs_f<ND, float>(g, tc, tc.wl, tc.wha, 1.f, aidx, ux, uy);   // which pairs exist (as counted)
+    make_pairs_f<ND, float>(g, tc, tc.wl, tc.wha, m, aidx, ax, ay);     // their weights, mask folded in
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {
-      const float wa = corner_weight_atom<ND, float>(tc, ci);   // validity folded in
-      if (wa != 0.f) {
-        const int q = corner_index<ND, float>(tc, ci);
-        if (!FILL) {
-          atomicAdd(cnt_or_cursor + (int64_t)b * g.S_i + q, 1);
-        } else {
-          const int pos = rowptr[(int64_t)b * (g.S_i + 1) + q] + atomicAdd(cnt_or_cursor + (int64_t)b * g.S_i + q, 1);
-          entries[(int64_t)b * ((int64_t)g.K * g.S_o * NC) + pos] =
-              make_int2(tap * g.S_o + pix, __float_as_int(wa * m));
-        }
+    for (int pi = 0; pi < NP; ++pi) {
+      if (ux[pi] != 0.f || uy[pi] != 0.f) {
+        const int q = aidx[pi];
+        const int pos = rowptr[(int64_t)seg * (g.S_i + 1) + q] + atomicAdd(cursor + (int64_t)seg * g.S_i + q, 1);
+        entries[(int64_t)seg * ((int64_t)g.K * g.S_o * NP) + pos] =
+            make_int4(tap * g.S_o + pix, __float_as_int(ax[pi]), __float_as_int(ay[pi]), 0);
       }
     }
   }
@@ -654,22 +662,29 @@ __global__ __launch_bounds__(256) void csr_scan_kernel(int S_i, const int *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. grad_input[b][c][q] += sum_{e in list(b, q)} w_e * gcol[b][src_e][c],  src = tap * S_o + pix
-// workgroup = 32 consecutive q of one image x 256 channels; wave w walks q = q0 + w, w + 4, ...
-// The list of q is fetched by ONE coalesced vector load (lane i <- entry i) and broadcast with
-// readlane, so there is no dependent scalar-load chain per entry.
+// 3. grad_input[b][c][q] (+)= sum over the entries e of anchor q of wx_e * gcol[b][src_e][c]
+//                           + sum over the entries e of anchor q-1 of wy_e * gcol[b][src_e][c]
+// workgroup = 32 consecutive q of one image x 256 channels; a wave WALKS a run of 8 consecutive
+// anchors with two accumulators per lane: `cur` (target = the anchor) and `nxt` (target = anchor
+// + 1); after an anchor, cur is the finished target, nxt becomes cur.  Every grad_col row is
+// thus read once per corner PAIR.  The run starts one anchor early to pick up the carry; rows of
+// the image need no special case: pairs never straddle a row (make_pairs), so the anchor in the
+// last column has an empty list and hands a zero carry to the next row.
+// The list of an anchor is fetched by ONE coalesced vector load (lane i <- entry i) and broadcast
+// with readlane, so there is no dependent scalar-load chain per entry.
 // ---------------------------------------------------------------------------------------------
+constexpr int kRun = 8;   // targets per wave run
+
 template <int ND>
 __global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float *__restrict__ gcol,
                                                             const int *__restrict__ rowptr,
-                                                            const int2 *__restrict__ entries,
+                                                            const int4 *__restrict__ entries,
                                                             float *__restrict__ grad_input) {
-  constexpr int NC = 1 << ND;
-  constexpr int QT = 32;
+  constexpr int NP = 1 << (ND - 1);
+  constexpr int QT = 4 * kRun;
   __shared__ float tile[256 * (QT + 1)];   // [c][q], pitch 33
   const int qtiles = (g.S_i + QT - 1) / QT;
-  // every grad_col row is read by up to 2^ND targets (q, q+1, q+W, ...): keep neighbouring q
-  // tiles on ONE XCD so those re-reads hit its L2 instead of HBM (3.7 GB -> ~1 GB at cfg2)
+  // keep neighbouring q tiles on ONE XCD: the rows they share are then re-read from its L2
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int b = bid / qtiles;
   const int q0 = (bid - b * qtiles) * QT;
@@ -679,52 +694,58 @@ __global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float 
   for (int cb = blockIdx.y * 256; cb < g.C; cb += gridDim.y * 256) {
     const int seg = b * g.DG + cb / g.Cdg;   // C_dg is a multiple of 256 here (or DG == 1)
     const int *rp = rowptr + (int64_t)seg * (g.S_i + 1);
-    const int2 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o * NC);
+    const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o * NP);
     const int c4 = cb + lane * 4;
     const int c_voff = (c4 < g.C ? c4 : 0) * 4;   // C % 4 == 0
-    for (int qi = wave; qi < QT; qi += 4) {
-      const int q = q0 + qi;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < g.S_i) {
-        const int e0 = __builtin_amdgcn_readfirstlane(rp[q]);
-        const int e1 = __builtin_amdgcn_readfirstlane(rp[q + 1]);
+    const int qs = q0 + wave * kRun;              // first target of this wave's run
+    float4 cur = make_float4(0.f, 0.f, 0.f, 0.f), nxt = cur;
+    for (int a = qs - 1; a < qs + kRun; ++a) {
+      if (a >= 0 && a < g.S_i) {
+        const int e0 = __builtin_amdgcn_readfirstlane(rp[a]);
+        const int e1 = __builtin_amdgcn_readfirstlane(rp[a + 1]);
         for (int base = e0; base < e1; base += 64) {
           const int cnt = min(64, e1 - base);
-          const int2 mine = (lane < cnt) ? ent[base + lane] : make_int2(0, 0);
-          // 16 independent row loads in flight per step (a one-entry-at-a-time loop serialises
-          // the full memory latency per entry: 0.65 ms at cfg2); lanes >= cnt hold weight 0, row 0
+          const int4 mine = (lane < cnt) ? ent[base + lane] : make_int4(0, 0, 0, 0);
+          // 16 independent row loads in flight per step; lanes >= cnt hold weights 0, row 0
           for (int i = 0; i < cnt; i += 16) {
             float4 v[16];
-            float we[16];
+            float wx[16], wy[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
               const int src = __builtin_amdgcn_readlane(mine.x, (i + u) & 63);
-              we[u] = __int_as_float(__builtin_amdgcn_readlane(mine.y, (i + u) & 63));
+              wx[u] = __int_as_float(__builtin_amdgcn_readlane(mine.y, (i + u) & 63));
+              wy[u] = __int_as_float(__builtin_amdgcn_readlane(mine.z, (i + u) & 63));
               v[u] = buf_load4(r_gc, c_voff, src * g.C * 4);
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-              acc.x = fmaf(we[u], v[u].x, acc.x); acc.y = fmaf(we[u], v[u].y, acc.y);
-              acc.z = fmaf(we[u], v[u].z, acc.z); acc.w = fmaf(we[u], v[u].w, acc.w);
+              cur.x = fmaf(wx[u], v[u].x, cur.x); cur.y = fmaf(wx[u], v[u].y, cur.y);
+              cur.z = fmaf(wx[u], v[u].z, cur.z); cur.w = fmaf(wx[u], v[u].w, cur.w);
+              nxt.x = fmaf(wy[u], v[u].x, nxt.x); nxt.y = fmaf(wy[u], v[u].y, nxt.y);
+              nxt.z = fmaf(wy[u], v[u].z, nxt.z); nxt.w = fmaf(wy[u], v[u].w, nxt.w);
             }
           }
         }
       }
-      float *tp = tile + (lane * 4) * (QT + 1) + qi;
-      tp[0] = acc.x; tp[QT + 1] = acc.y; tp[2 * (QT + 1)] = acc.z; tp[3 * (QT + 1)] = acc.w;
+      if (a >= qs) {
+        float *tp = tile + (lane * 4) * (QT + 1) + (a - q0);
+        tp[0] = cur.x; tp[QT + 1] = cur.y; tp[2 * (QT + 1)] = cur.z; tp[3 * (QT + 1)] = cur.w;
+      }
+      cur = nxt;
+      nxt = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     // transpose out: thread = (channel, 8 consecutive q); a wave covers 8 channels x 32 q
     {
-      const int cl = threadIdx.x >> 2, qs = (threadIdx.x & 3) * 8;
+      const int cl = threadIdx.x >> 2, qs8 = (threadIdx.x & 3) * 8;
       for (int cc = cl; cc < 256; cc += 64) {
         const int c = cb + cc;
         if (c < g.C) {
-          float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q0 + qs;
-          const float *src = tile + cc * (QT + 1) + qs;
+          float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q0 + qs8;
+          const float *src = tile + cc * (QT + 1) + qs8;
 #pragma unroll
           for (int k = 0; k < 8; ++k)
-            if (q0 + qs + k < g.S_i) dst[k] = g.acc_data ? dst[k] + src[k] : src[k];
+            if (q0 + qs8 + k < g.S_i) dst[k] = g.acc_data ? dst[k] + src[k] : src[k];
         }
       }
     }
@@ -732,20 +753,21 @@ __global__ __launch_bounds__(256) void col2im_gather_kernel(Geom g, const float 
   }
 }
 
-
 // Deformable groups narrower than 256 channels: LPD = C_dg / 4 lanes cover one group, so a wave
-// walks 64 / LPD input pixels of ONE group at a time (lane = (pixel j, channel quad r)); each lane
-// group follows its own list.  List entries are fetched LPD at a time (lane r <- entry r) and
-// broadcast inside the lane group with a width-limited shuffle.
+// walks 64 / LPD runs of ONE group at a time (lane = (run j, channel quad r)); each lane group
+// follows its own lists.  Entries are fetched LPD at a time (lane r <- entry r) and broadcast
+// inside the lane group with a width-limited shuffle.
 template <int ND, int LPD>
 __global__ __launch_bounds__(256) void col2im_gather_grouped_kernel(
     Geom g, const float *__restrict__ gcol, const int *__restrict__ rowptr,
-    const int2 *__restrict__ entries, float *__restrict__ grad_input) {
-  constexpr int NC = 1 << ND;
-  constexpr int QT = 32, NQ = 64 / LPD;   // q per tile, q per wave step
-  constexpr int CDG = LPD * 4;             // channels per deformable group
-  constexpr int DPB = 256 / CDG;           // groups per 256-channel block
-  __shared__ float tile[256 * (QT + 1)];   // [c][q], pitch 33
+    const int4 *__restrict__ entries, float *__restrict__ grad_input) {
+  constexpr int NP = 1 << (ND - 1);
+  constexpr int QT = 4 * kRun, NQ = 64 / LPD;   // targets per tile, runs per wave
+  constexpr int CDG = LPD * 4;                    // channels per deformable group
+  constexpr int DPB = 256 / CDG;                  // groups per 256-channel block
+  constexpr int RPT = QT / kRun;                  // runs per tile (4)
+  constexpr int UB = LPD < 16 ? LPD : 16;         // row loads in flight per step
+  __shared__ float tile[256 * (QT + 1)];          // [c][q], pitch 33
   const int qtiles = (g.S_i + QT - 1) / QT;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int b = bid / qtiles;
@@ -754,53 +776,63 @@ __global__ __launch_bounds__(256) void col2im_gather_grouped_kernel(
   const int j = lane / LPD, r = lane % LPD;
   const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * g.C, (size_t)g.K * g.S_o * g.C * 4);
   for (int cb = 0; cb < g.C; cb += 256) {
-    // work items of the block: (group d of DPB) x (q step of QT / NQ)
-    for (int item = wave; item < DPB * (QT / NQ); item += 4) {
-      const int d = item / (QT / NQ), qi = (item % (QT / NQ)) * NQ + j;
+    // work items of the block: (group d of DPB) x (RPT / NQ sets of NQ runs)
+    for (int item = wave; item < DPB * (RPT / NQ); item += 4) {
+      const int d = item / (RPT / NQ), run = (item % (RPT / NQ)) * NQ + j;
       const int c4 = cb + d * CDG + r * 4;
-      const int q = q0 + qi;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool on = q < g.S_i && c4 < g.C;
+      const int qs = q0 + run * kRun;
+      const bool chan_on = c4 < g.C;
       const int seg = b * g.DG + min(c4, g.C - 1) / g.Cdg;
       const int *rp = rowptr + (int64_t)seg * (g.S_i + 1);
-      const int2 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o * NC);
-      const int e0 = on ? rp[q] : 0, e1 = on ? rp[q + 1] : 0;
-      const int c_voff = (c4 < g.C ? c4 : 0) * 4;
-      for (int base = e0; __any(base < e1); base += LPD) {
-        const int cnt = max(0, min(LPD, e1 - base));
-        const int2 mine = (r < cnt) ? ent[base + r] : make_int2(0, 0);   // weight 0, row 0 beyond
-        constexpr int UB = LPD < 16 ? LPD : 16;   // row loads in flight per step
+      const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o * NP);
+      const int c_voff = (chan_on ? c4 : 0) * 4;
+      float4 cur = make_float4(0.f, 0.f, 0.f, 0.f), nxt = cur;
+      for (int step = 0; step <= kRun; ++step) {
+        const int a = qs - 1 + step;
+        const bool on = chan_on && a >= 0 && a < g.S_i;
+        const int e0 = on ? rp[a] : 0, e1 = on ? rp[a + 1] : 0;
+        for (int base = e0; __any(base < e1); base += LPD) {
+          const int cnt = max(0, min(LPD, e1 - base));
+          const int4 mine = (r < cnt) ? ent[base + r] : make_int4(0, 0, 0, 0);   // weights 0, row 0 beyond
 #pragma unroll
-        for (int u0 = 0; u0 < LPD; u0 += UB) {
-          float4 v[UB];
-          float we[UB];
+          for (int u0 = 0; u0 < LPD; u0 += UB) {
+            float4 v[UB];
+            float wx[UB], wy[UB];
 #pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            const int src = __shfl(mine.x, u0 + u, LPD);
-            we[u] = __int_as_float(__shfl(mine.y, u0 + u, LPD));
-            v[u] = buf_load4(r_gc, src * g.C * 4 + c_voff, 0);
-          }
+            for (int u = 0; u < UB; ++u) {
+              const int src = __shfl(mine.x, u0 + u, LPD);
+              wx[u] = __int_as_float(__shfl(mine.y, u0 + u, LPD));
+              wy[u] = __int_as_float(__shfl(mine.z, u0 + u, LPD));
+              v[u] = buf_load4(r_gc, src * g.C * 4 + c_voff, 0);
+            }
 #pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            acc.x = fmaf(we[u], v[u].x, acc.x); acc.y = fmaf(we[u], v[u].y, acc.y);
-            acc.z = fmaf(we[u], v[u].z, acc.z); acc.w = fmaf(we[u], v[u].w, acc.w);
+            for (int u = 0; u < UB; ++u) {
+              cur.x = fmaf(wx[u], v[u].x, cur.x); cur.y = fmaf(wx[u], v[u].y, cur.y);
+              cur.z = fmaf(wx[u], v[u].z, cur.z); cur.w = fmaf(wx[u], v[u].w, cur.w);
+              nxt.x = fmaf(wy[u], v[u].x, nxt.x); nxt.y = fmaf(wy[u], v[u].y, nxt.y);
+              nxt.z = fmaf(wy[u], v[u].z, nxt.z); nxt.w = fmaf(wy[u], v[u].w, nxt.w);
+            }
           }
         }
+        if (step > 0) {
+          float *tp = tile + (d * CDG + r * 4) * (QT + 1) + (a - q0);
+          tp[0] = cur.x; tp[QT + 1] = cur.y; tp[2 * (QT + 1)] = cur.z; tp[3 * (QT + 1)] = cur.w;
+        }
+        cur = nxt;
+        nxt = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      float *tp = tile + (d * CDG + r * 4) * (QT + 1) + qi;
-      tp[0] = acc.x; tp[QT + 1] = acc.y; tp[2 * (QT + 1)] = acc.z; tp[3 * (QT + 1)] = acc.w;
     }
     __syncthreads();
     {
-      const int cl = threadIdx.x >> 2, qs = (threadIdx.x & 3) * 8;
+      const int cl = threadIdx.x >> 2, qs8 = (threadIdx.x & 3) * 8;
       for (int cc = cl; cc < 256; cc += 64) {
         const int c = cb + cc;
         if (c < g.C) {
-          float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q0 + qs;
-          const float *src = tile + cc * (QT + 1) + qs;
+          float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q0 + qs8;
+          const float *src = tile + cc * (QT + 1) + qs8;
 #pragma unroll
           for (int k = 0; k < 8; ++k)
-            if (q0 + qs + k < g.S_i) dst[k] = g.acc_data ? dst[k] + src[k] : src[k];
+            if (q0 + qs8 + k < g.S_i) dst[k] = g.acc_data ? dst[k] + src[k] : src[k];
         }
       }
     }
@@ -900,9 +932,9 @@ int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *
   hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
   if ((rc = check_launch("zero_cnt"))) return rc;
 #define LAUNCH_CSR(ND, MOD)                                                                     \
-  hipLaunchKernelGGL((csr_pass_kernel<ND, MOD, true>), dim3(grid_for(samples)), dim3(256), 0,   \
-                     stream, g, (const float *)t.offset, (const float *)t.mask, cnt, rowptr,    \
-                     (int2 *)entries)
+  hipLaunchKernelGGL((csr_fill_kernel<ND, MOD>), dim3(grid_for(samples)), dim3(256), 0, stream,  \
+                     g, (const float *)t.offset, (const float *)t.mask, cnt, rowptr,            \
+                     (int4 *)entries)
   if (g.nd == 2) { if (g.modulated) LAUNCH_CSR(2, true); else LAUNCH_CSR(2, false); }
   else { if (g.modulated) LAUNCH_CSR(3, true); else LAUNCH_CSR(3, false); }
 #undef LAUNCH_CSR
@@ -915,17 +947,17 @@ int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *ro
   const dim3 grid(g.B * qtiles, 1);
 #define LAUNCH_GG(ND, LPD)                                                                      \
   hipLaunchKernelGGL((col2im_gather_grouped_kernel<ND, LPD>), grid, dim3(256), 0, stream, g,    \
-                     gcol, rowptr, (const int2 *)entries, (float *)t.grad_input)
+                     gcol, rowptr, (const int4 *)entries, (float *)t.grad_input)
   if (g.DG > 1 && g.Cdg == 64) {
     if (g.nd == 2) LAUNCH_GG(2, 16); else LAUNCH_GG(3, 16);
   } else if (g.DG > 1 && g.Cdg == 128) {
     if (g.nd == 2) LAUNCH_GG(2, 32); else LAUNCH_GG(3, 32);
   } else if (g.nd == 2) {
     hipLaunchKernelGGL((col2im_gather_kernel<2>), grid, dim3(256), 0, stream, g, gcol, rowptr,
-                       (const int2 *)entries, (float *)t.grad_input);
+                       (const int4 *)entries, (float *)t.grad_input);
   } else {
     hipLaunchKernelGGL((col2im_gather_kernel<3>), grid, dim3(256), 0, stream, g, gcol, rowptr,
-                       (const int2 *)entries, (float *)t.grad_input);
+                       (const int4 *)entries, (float *)t.grad_input);
   }
 #undef LAUNCH_GG
   return check_launch("col2im_gather");

@@ -123,7 +123,7 @@ BwdDims bwd_dims(const Geom &g) {
   bd.off_gcol = off; off += align_up((size_t)g.B * g.C * g.K * g.S_o * sizeof(float));
   bd.off_cnt = off;  off += align_up((size_t)g.B * g.DG * g.S_i * sizeof(int));
   bd.off_rowptr = off; off += align_up((size_t)g.B * g.DG * (g.S_i + 1) * sizeof(int));
-  bd.off_entries = off; off += align_up((size_t)g.B * g.DG * g.K * g.S_o * nc * 8);
+  bd.off_entries = off; off += align_up((size_t)g.B * g.DG * g.K * g.S_o * (nc / 2) * 16);
   bd.bias_tiles = (g.N + 32 * (4 / bd.waves_c) - 1) / (32 * (4 / bd.waves_c));
   bd.off_bias = off; off += align_up((size_t)bd.bias_tiles * g.O * sizeof(float));
   bd.off_end = off;
