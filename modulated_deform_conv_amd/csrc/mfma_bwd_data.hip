@@ -18,16 +18,17 @@
 //     channels), for step 3.  The kernel also emits grad_out in the fragment order GEMM-2 wants
 //     and runs the counting pass of step 2.
 //  2. inverted scatter map  (count [inside step 1] -> scan -> fill, integer atomics only):
-//     for every (image, deformable group, input pixel q) the list of
-//     (tap * S_o + output pixel, bilinear weight * mask) that land on q.  Depends only on
+//     for every (image, deformable group, input pixel q) the list of corner PAIRS anchored at q:
+//     (tap * S_o + output pixel, weight * mask on q, weight * mask on q + 1).  Depends only on
 //     offset / mask.
 //  3. col2im_gather_kernel / col2im_gather_grouped_kernel
-//     grad_input[b][c][q] += sum over the lists of q of weight * grad_col[b][tap][n][c]:
-//     one WAVE per input pixel q, lanes = channels (4 each), so every list entry is one
+//     grad_input[b][c][q] (+)= sum over the list of q of wx * grad_col[b][tap][n][c]
+//                            + sum over the list of q-1 of wy * grad_col[b][tap][n][c]:
+//     a WAVE walks 8 consecutive anchors, lanes = channels (4 each), so every list entry is one
 //     wave-uniform scalar read plus one fully coalesced 16 B/lane vector read of all channels --
-//     no divergence, no atomics; a 32-pixel tile is transposed through LDS and added to the
+//     no divergence, no atomics; a 32-pixel tile is transposed through LDS and written to the
 //     NCHW grad_input with whole-line accesses.  (A first version with lanes = pixels and
-//     per-lane list walks took 3.5 ms at cfg2; this one is HBM-bound.)
+//     per-lane list walks took 3.5 ms at cfg2, one list entry per CORNER 0.43 ms; now 0.25 ms.)
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
 #include <algorithm>
