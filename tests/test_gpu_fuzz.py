@@ -1,0 +1,75 @@
+"""Seeded random shapes: the MFMA path against the direct path (two independent implementations of
+the same semantics) and, for the smaller half, against the CPU oracle.  Catches edge cases the
+hand-picked cases miss: ragged channel counts, batch tails, odd extents, stride / dilation /
+padding mixes, conv groups and deformable groups on the matrix-core backward."""
+import random
+
+import pytest
+import torch
+
+from tests.cases import D2, D3, M2, M3, _c, make_inputs
+from tests.util import assert_close, run_oracle, run_product
+
+pytestmark = pytest.mark.gpu
+
+_PATHS = []   # (forward path, backward path) of every case run with path selection on "auto"
+
+
+def _random_case(seed):
+    r = random.Random(seed)
+    nd = r.choice([2, 2, 2, 3])
+    modulated = r.random() < 0.6
+    op = {(2, False): D2, (2, True): M2, (3, False): D3, (3, True): M3}[(nd, modulated)]
+    groups = r.choice([1, 1, 1, 2, 4])
+    dg_choice = r.choice([1, 1, 2])
+    # channels: multiples of 8 (MFMA backward), >= 16, divisible by groups and deformable groups
+    if dg_choice > 1:
+        cdg = r.choice([64, 128])
+        C = cdg * dg_choice
+        while C % groups:
+            groups //= 2
+    else:
+        C = r.choice([16, 24, 32, 40, 48, 64, 72, 96, 136]) * (1 if r.random() < 0.8 else 2)
+        while C % groups:
+            groups = max(1, groups // 2)
+    O = r.choice([16, 17, 20, 32, 33, 48, 64, 80, 130]) * groups // groups
+    O = (O + groups - 1) // groups * groups
+    k = r.choice([1, 2, 3, 3, 3]) if nd == 2 else r.choice([1, 2, 3])
+    stride = r.choice([1, 1, 2])
+    dil = r.choice([1, 1, 2])
+    pad = r.choice([0, 1, dil * (k - 1) // 2 + (1 if k > 1 else 0)])
+    lo = dil * (k - 1) + 1
+    size = tuple(r.randint(max(lo, 3), 13 if nd == 2 else 7) for _ in range(nd))
+    size = size[:-1] + (max(size[-1], 2),)
+    B = r.choice([1, 2, 3])
+    return _c("fuzz%d" % seed, op, B, C, O, size, k, stride=stride, padding=pad, dilation=dil,
+              groups=groups, dgroups=dg_choice, in_step=r.choice([1, 2, 64]), bias=r.random() < 0.5,
+              tier="medium", seed=500 + seed, offset_scale=r.choice([0.5, 1.0, 3.0]))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_mfma_equals_direct_and_oracle_on_random_shapes(seed):
+    case = _random_case(seed)
+    t = make_inputs(case, device="cuda")
+    out_a, g_a, paths = run_product(case, t, "auto")
+    _PATHS.append(tuple(paths))
+    out_d, g_d, _ = run_product(case, t, "direct")
+    assert_close("output", out_a, out_d, 1e-4)
+    for k, v in g_a.items():
+        if v is not None and g_d[k] is not None:
+            assert_close(k, v, g_d[k], 1e-4)
+    if seed % 2 == 0:
+        want_out, want = run_oracle(case, t, torch.float32)
+        assert_close("output/oracle", out_a, want_out, 1e-4)
+        for k, v in g_a.items():
+            if v is not None and want[k] is not None:
+                assert_close(k + "/oracle", v, want[k], 1e-4)
+
+
+def test_fuzz_exercises_the_matrix_core_path():
+    """The random shapes are drawn so that most of them qualify for the MFMA kernels."""
+    if len(_PATHS) < 40:
+        pytest.skip("needs the 40 random cases of this module in the same session")
+    bwd = sum(1 for p in _PATHS if p[1] == "mfma")
+    fwd = sum(1 for p in _PATHS if p[0] == "mfma")
+    assert bwd >= 30 and fwd >= 20, (fwd, bwd)
