@@ -1,0 +1,295 @@
+// mfma_fwd_cl.hip -- forward implicit GEMM with CHANNELS-LAST gathers (fp32, gfx950).
+//
+// Same contraction and tiling idea as mfma_fwd.hip, but the column operand is sampled from a
+// channels-last copy of the input, xt[b][q][c] (made once per call by `nchw_to_nhwc`):
+//
+//   * with NCHW input every lane of a deformable gather lands in its own cache line as soon as
+//     the offsets are data dependent -- about 14 lines per 64-lane load in 2-D and 40-64 in 3-D
+//     (every lane has its own (dh, dw) row), which is what bounds the 3-D kernels;
+//   * in xt one corner of 64 channels is ONE 256-byte segment: a thread fetches 4 consecutive
+//     channels of a corner with a 16-byte load, 16 threads cover the corner, a 64-lane load
+//     touches 4 corners = 8 lines.  Per sample that is the same number of load instructions as
+//     the paired NCHW loads in 3-D (and half in 2-D), at a fraction of the lines.
+//
+// K slab = 64 channels of one tap (4 MFMA sub-chunks of 16, the packed weights keep their
+// 16-channel chunking), so there is one barrier per 64 channels instead of one per 16.
+// The sampling state of (tap, pixel) -- 2^ND corner byte offsets into xt and 2^ND weights with
+// validity and mask folded in -- is built by BN threads two taps ahead and parked in LDS; the
+// gathers of slab s+1 are issued pixel by pixel between the MFMA sub-chunks of slab s.
+//
+// Used for 3-D shapes with C_in/groups a multiple of 64 and one deformable group (where the
+// gathers dominate: DESIGN.md section 4); MDCONV_FWD_CL=0/1 forces it off / on for 2-D too.
+#include "mfma_kernels.hpp"
+#include "mfma_tile.hpp"
+
+#include <stdlib.h>
+
+namespace mdconv {
+
+namespace {
+
+constexpr int kSlab = 64;   // channels per LDS slab
+
+// xt[b][q][c] = x[b][c][q]   (32 x 32 tiles through LDS; C is a multiple of 32 here)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(int C, int S, const float *__restrict__ x,
+                                                           float *__restrict__ xt) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, q0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
+  const float *src = x + ((size_t)b * C + c0) * S;
+  float *dst = xt + ((size_t)b * S + q0) * C + c0;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) t[r][tx] = (q0 + tx < S) ? src[(size_t)r * S + q0 + tx] : 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (q0 + r < S) dst[(size_t)r * C + tx] = t[tx][r];
+}
+
+template <int ND, bool MOD, int BM, int BN, int WM>
+__global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd,
+                                                             const float *__restrict__ xt,
+                                                             const float *__restrict__ wp,
+                                                             const float *__restrict__ bias,
+                                                             const float *__restrict__ offset,
+                                                             const float *__restrict__ mask,
+                                                             float *__restrict__ output, int ntm,
+                                                             int ntn) {
+  constexpr int NC = 1 << ND;
+  constexpr int MB = WM / 32;
+  constexpr int WAVES_M = BM / WM, WAVES_N = 4 / WAVES_M;
+  static_assert(WAVES_M * WAVES_N == 4 && BN == 32 * WAVES_N, "tile shape");
+  constexpr int PPT = BN / 16;       // pixels per thread per slab (2 or 4)
+  constexpr int BNP = BN + 1;        // LDS pitch of a channel row
+  constexpr int SW = 2 * NC;         // state words per pixel
+  __shared__ __attribute__((aligned(16))) float Bs[2 * kSlab * BNP];
+  __shared__ __attribute__((aligned(16))) float St[3 * BN * SW];
+
+  const int grp = blockIdx.y;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tn = tile / ntm, tm = tile - tn * ntm;
+  const int o0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 32;
+  const int cq = tid & 15, pg = tid >> 4;   // channel quad of the slab, pixel group
+
+  const int spt = g.Cg / kSlab;             // slabs per tap
+  const int S = g.K * spt;
+  const int cchunks = pd.Cgp / kBK;
+  const int mblks = pd.Ogp / 32;
+  const int slab_bytes = mblks * 2 * 64 * 16;   // one 16-channel chunk of packed weights
+  const rsrc_t r_xt = make_rsrc(xt, (size_t)g.B * g.S_i * g.C * sizeof(float));
+  const rsrc_t r_wp = make_rsrc(wp + (size_t)grp * g.K * cchunks * (slab_bytes / 4),
+                                (size_t)g.K * cchunks * slab_bytes);
+  const int a_voff = (((o0 + wm0) / 32) * 2 * 64 + lane) * 16;
+  const int c_voff = (grp * g.Cg + cq * 4) * 4;   // this thread's channel quad inside a corner row
+
+  // ---- sampling state: thread p < BN owns pixel n0 + p ----
+  const int n_s = min(n0 + (tid < BN ? tid : 0), g.N - 1);
+  const int b_s = n_s / g.S_o, pix_s = n_s - b_s * g.S_o;
+  int oc[ND];
+  out_coords<ND>(g, pix_s, oc);
+  float dl[ND], ml = 1.f;   // offsets / mask of the tap whose state is built next
+  auto fetch_tap = [&](int tap) {
+    if (tid < BN) {
+      const int64_t ob = ((int64_t)b_s * (ND * g.K) + ND * tap) * g.S_o + pix_s;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) dl[a] = offset[ob + (int64_t)a * g.S_o];
+      if (MOD) ml = mask[((int64_t)b_s * g.K + tap) * g.S_o + pix_s];
+    }
+  };
+  auto build_state = [&](int tap) {   // from dl / ml, into slot tap % 3
+    if (tid < BN) {
+      int tcd[ND];
+      tap_coords<ND>(g, tap, tcd);
+      TapCoef<ND, float> tc;
+      make_tap<ND, float>(g, oc, tcd, dl, false, tc);
+      float *sp = St + ((tap % 3) * BN + tid) * SW;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        sp[ci] = __int_as_float((b_s * g.S_i + corner_index<ND, float>(tc, ci)) * g.C * 4);
+        sp[NC + ci] = corner_weight<ND, float>(tc, ci) * ml;
+      }
+    }
+  };
+
+  f32x16 acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // ---- gather / blend of ONE pixel of a slab (2^ND 16-byte loads per thread) ----
+  struct Px { float4 v[NC]; };
+  auto issue_px = [&](Px &px, int tap, int c0, int p) {
+    const float *sp = St + ((tap % 3) * BN + p) * SW;
+    int co[NC];
+#pragma unroll
+    for (int h = 0; h < NC / 4; ++h) {
+      const float4 o4 = *reinterpret_cast<const float4 *>(sp + 4 * h);
+      co[4 * h + 0] = __float_as_int(o4.x); co[4 * h + 1] = __float_as_int(o4.y);
+      co[4 * h + 2] = __float_as_int(o4.z); co[4 * h + 3] = __float_as_int(o4.w);
+    }
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) px.v[ci] = buf_load4(r_xt, co[ci] + c_voff, c0 * 4);
+  };
+  auto commit_px = [&](const Px &px, int tap, int p, float *Bb) {
+    const float *sp = St + ((tap % 3) * BN + p) * SW + NC;
+    float w[NC];
+#pragma unroll
+    for (int h = 0; h < NC / 4; ++h) {
+      const float4 w4 = *reinterpret_cast<const float4 *>(sp + 4 * h);
+      w[4 * h + 0] = w4.x; w[4 * h + 1] = w4.y; w[4 * h + 2] = w4.z; w[4 * h + 3] = w4.w;
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+      s.x = fmaf(w[ci], px.v[ci].x, s.x); s.y = fmaf(w[ci], px.v[ci].y, s.y);
+      s.z = fmaf(w[ci], px.v[ci].z, s.z); s.w = fmaf(w[ci], px.v[ci].w, s.w);
+    }
+    float *d = Bb + (cq * 4) * BNP + p;
+    d[0] = s.x; d[BNP] = s.y; d[2 * BNP] = s.z; d[3 * BNP] = s.w;
+  };
+  auto load_a = [&](float4 (&ra)[MB][2], int chunk) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) ra[i][q] = buf_load4(r_wp, a_voff + (i * 2 + q) * 1024, chunk * slab_bytes);
+  };
+  auto mma = [&](const float4 (&ra)[MB][2], const float *Bsub) {   // Bsub: 16 channel rows
+    const float *Bb = Bsub + wn0 + (lane & 31) + 4 * kh * BNP;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float b = Bb[(8 * q + s) * BNP];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+      }
+  };
+
+  // ---- prologue: states of taps 0 and 1, slab 0 into Bs[0] ----
+  fetch_tap(0);
+  build_state(0);
+  if (g.K > 1) {
+    fetch_tap(1);
+    build_state(1);
+  }
+  if (g.K > 2) fetch_tap(2);   // consumed while the first slab is multiplied
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    Px px;
+    issue_px(px, 0, 0, pg + 16 * i);
+    commit_px(px, 0, pg + 16 * i, Bs);
+  }
+  float4 ra0[MB][2], ra1[MB][2];
+  load_a(ra0, 0);
+  __syncthreads();
+
+  int tap = 0, cs = 0;   // tap and slab-in-tap of slab s
+  for (int s = 0; s < S; ++s) {
+    // slab s+1; after the last slab: a harmless repeat of slab s into the unused buffer
+    int tapn = tap, csn = cs + 1;
+    if (csn == spt) { csn = 0; ++tapn; }
+    const bool last = s + 1 == S;
+    const int tap1 = last ? tap : tapn, cs1 = last ? cs : csn;
+    const float *Bcur = Bs + (s & 1) * kSlab * BNP;
+    float *Bnxt = Bs + ((s + 1) & 1) * kSlab * BNP;
+    const int chunk0 = tap * cchunks + cs * 4;       // first 16-channel chunk of slab s
+    const int chunk_n = tap1 * cchunks + cs1 * 4;    // ... of slab s+1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // the pixel of slab s+1 handled around sub-chunk j
+      const bool has_px = PPT == 4 || (j & 1) == 0;
+      const int p = pg + 16 * (PPT == 4 ? j : j / 2);
+      Px px;
+      // A fragments first, gathers second: vmcnt retires in order (mfma_fwd.hip)
+      if (j == 0) load_a(ra1, chunk0 + 1);
+      if (j == 1) load_a(ra0, chunk0 + 2);
+      if (j == 2) load_a(ra1, chunk0 + 3);
+      if (j == 3) load_a(ra0, chunk_n);
+      if (has_px) issue_px(px, tap1, cs1 * kSlab, p);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j & 1) mma(ra1, Bcur + (16 * j) * BNP);
+      else mma(ra0, Bcur + (16 * j) * BNP);
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_px) commit_px(px, tap1, p, Bnxt);
+      if (j == 1 && cs == 0) {
+        // first slab of a tap: build the state of tap + 2 (its offsets were requested one tap
+        // ago) and request the offsets of tap + 3
+        if (tap + 2 < g.K) build_state(tap + 2);
+        if (tap + 3 < g.K) fetch_tap(tap + 3);
+      }
+    }
+    __syncthreads();
+    tap = tapn;
+    cs = csn;
+  }
+
+  // ---- epilogue: + bias, store [B, O, S_o] (lanes 0-31 -> 32 consecutive pixels) ----
+  const int n_e = n0 + wn0 + (lane & 31);
+  if (n_e < g.N) {
+    const int b_e = n_e / g.S_o;
+    const int pix_e = n_e - b_e * g.S_o;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ol = o0 + wm0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (ol < g.Og) {
+          const int och = grp * g.Og + ol;
+          const float bv = g.with_bias ? bias[och] : 0.f;
+          output[(int64_t)(b_e * g.O + och) * g.S_o + pix_e] = acc[mb][r] + bv;
+        }
+      }
+  }
+}
+
+template <int ND, bool MOD, int BM, int BN, int WM>
+int launch_cl(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, const float *xt,
+              hipStream_t stream) {
+  const int ntm = (g.Og + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+  hipLaunchKernelGGL((mfma_fwd_cl_kernel<ND, MOD, BM, BN, WM>), dim3(ntm * ntn, g.G), dim3(256), 0,
+                     stream, g, pd, xt, wp, (const float *)t.bias, (const float *)t.offset,
+                     (const float *)t.mask, (float *)t.output, ntm, ntn);
+  return check_launch("mfma_fwd_cl");
+}
+
+template <int ND, bool MOD>
+int launch_cl_tiles(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+                    const float *xt, hipStream_t stream) {
+  if (pd.BM == 256) return launch_cl<ND, MOD, 256, 32, 64>(g, pd, t, wp, xt, stream);
+  if (pd.BM == 128) return launch_cl<ND, MOD, 128, 64, 64>(g, pd, t, wp, xt, stream);
+  return launch_cl<ND, MOD, 64, 64, 32>(g, pd, t, wp, xt, stream);
+}
+
+}  // namespace
+
+bool fwd_channels_last(const Geom &g) {
+  if (g.DG != 1 || g.Cg % kSlab) return false;
+  if (const char *e = getenv("MDCONV_FWD_CL")) return atoi(e) != 0;
+  return g.nd == 3;
+}
+
+size_t fwd_cl_bytes(const Geom &g) { return (size_t)g.B * g.S_i * g.C * sizeof(float); }
+
+int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+                        float *xt, hipStream_t stream) {
+  const dim3 tg((g.S_i + 31) / 32, g.C / 32, g.B);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, tg, dim3(256), 0, stream, g.C, g.S_i,
+                     (const float *)t.input, xt);
+  int rc = check_launch("nchw_to_nhwc");
+  if (rc) return rc;
+  if (g.nd == 2)
+    return g.modulated ? launch_cl_tiles<2, true>(g, pd, t, wp, xt, stream)
+                       : launch_cl_tiles<2, false>(g, pd, t, wp, xt, stream);
+  return g.modulated ? launch_cl_tiles<3, true>(g, pd, t, wp, xt, stream)
+                     : launch_cl_tiles<3, false>(g, pd, t, wp, xt, stream);
+}
+
+}  // namespace mdconv

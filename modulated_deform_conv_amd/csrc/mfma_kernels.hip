@@ -172,7 +172,9 @@ Geom chunk_geom(const Geom &g, int bc) {
 size_t core_bytes_for(const Geom &gc, bool backward) {
   if (backward) return bwd_dims(gc).off_end;
   const PackDims pd = pack_dims(gc);
-  return align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float));
+  size_t n = align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float));
+  if (fwd_channels_last(gc)) n += align_up(fwd_cl_bytes(gc));   // NHWC copy of the input chunk
+  return n;
 }
 
 bool make_plan(const Geom &g, int dtype, bool backward, Plan *p) {
@@ -343,7 +345,12 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
       tc.input = x; tc.offset = of; tc.mask = mk; tc.output = out;
     }
     profile_mark(0, true, stream);
-    rc = mfma_forward_f32(gc, pd, tc, wp, stream);
+    if (fwd_channels_last(gc)) {
+      float *xt = (float *)(base + align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float)));
+      rc = mfma_forward_cl_f32(gc, pd, tc, wp, xt, stream);
+    } else {
+      rc = mfma_forward_f32(gc, pd, tc, wp, stream);
+    }
     profile_mark(0, false, stream);
     if (rc) return rc;
     if (p.half_io && (rc = narrow((const float *)tc.output, out, (int64_t)bc * g.O * g.S_o, false, stream)))

@@ -96,6 +96,11 @@ int pack_weights_f32(const Geom &g, const PackDims &pd, const float *weight, flo
                      hipStream_t stream);
 int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
                      hipStream_t stream);
+// channels-last gathers (mfma_fwd_cl.hip): xt = scratch for the NHWC copy of the input
+bool fwd_channels_last(const Geom &g);
+size_t fwd_cl_bytes(const Geom &g);
+int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+                        float *xt, hipStream_t stream);
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, hipStream_t stream);
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);

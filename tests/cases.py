@@ -61,6 +61,11 @@ CASES = [
     _c("mfma_dcn3d_k1x3x3_s2_c32_o32", D3, 1, 32, 32, (4, 9, 10), (1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1),
        tier="medium", seed=44),
     _c("mfma_mdcn2d_big_offsets_c32", M2, 2, 32, 32, (8, 9), 3, tier="medium", seed=45, offset_scale=5.0),
+    # channels-last forward (mfma_fwd_cl.hip): 3-D, C_in/groups a multiple of 64, all three tiles
+    _c("cl_dcn3d_c64_o64_6x7x6", D3, 2, 64, 64, (6, 7, 6), 3, tier="medium", seed=51),
+    _c("cl_mdcn3d_c128_o128_dil2", M3, 1, 128, 128, (4, 6, 5), 3, padding=2, dilation=2, bias=False, tier="medium", seed=52),
+    _c("cl_dcn3d_c64_o264_s2", D3, 2, 64, 264, (5, 5, 6), 3, stride=2, tier="medium", seed=53),
+    _c("cl_mdcn3d_g2_c128_o64_k2", M3, 1, 128, 64, (5, 4, 6), 2, padding=1, groups=2, tier="medium", seed=54),
     # medium: down-scaled analogues of BASELINE.json configs[1..4] (same K / stride / dilation /
     # G : DG structure, channel counts that exercise the MFMA tiles incl. ragged edges)
     _c("cfg2s_mdcn2d_c64_28x28_b4", M2, 4, 64, 64, (28, 28), 3, tier="medium", seed=21),
