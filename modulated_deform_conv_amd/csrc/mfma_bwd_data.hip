@@ -315,8 +315,13 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
         int ev[2 * NC];
 #pragma unroll
         for (int pi = 0; pi < NP; ++pi) {
-          ev[pi] = pp.live ? (pp.b * g.C * g.S_i + pidx[pi]) * 4 : 0;
-          ev[NP + pi] = 0;
+          if (bd.cl) {   // channels-last GEMM-2: byte offsets of both corners into xt[b][q][c]
+            ev[2 * pi] = pp.live ? (pp.b * g.S_i + pidx[pi]) * g.C * 4 : 0;
+            ev[2 * pi + 1] = pp.live ? (pp.b * g.S_i + pidx[pi] + 1) * g.C * 4 : 0;
+          } else {
+            ev[pi] = pp.live ? (pp.b * g.C * g.S_i + pidx[pi]) * 4 : 0;
+            ev[NP + pi] = 0;
+          }
           ev[NC + 2 * pi] = pp.live ? __float_as_int(px[pi] * m_n) : 0;
           ev[NC + 2 * pi + 1] = pp.live ? __float_as_int(py[pi] * m_n) : 0;
         }

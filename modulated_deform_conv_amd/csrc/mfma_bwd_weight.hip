@@ -267,10 +267,15 @@ int grid_for(int64_t total) {
 }  // namespace
 
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
-                        const int *table, float *part, const float *bias_part, hipStream_t stream) {
+                        const int *table, float *part, const float *bias_part, const float *xt,
+                        hipStream_t stream) {
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
   const bool padn = bd.Np != g.N;
   profile_mark(2, true, stream);
+  if (bd.cl) {
+    const int rcl = mfma_bwd_weight_cl_launch(g, bd, xt, ga, table, part, stream);
+    if (rcl) return rcl;
+  } else {
 #define LAUNCH_BW(ND, PADN, WR, WC, MB)                                                         \
   hipLaunchKernelGGL((mfma_bwd_weight_kernel<ND, PADN, WR, WC, MB>), grid, dim3(256), 0, stream, \
                      g, bd, (const float *)t.input, ga, table, part)
@@ -282,6 +287,7 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
   else { if (padn) LAUNCH_BW2(3, true); else LAUNCH_BW2(3, false); }
 #undef LAUNCH_BW2
 #undef LAUNCH_BW
+  }
   profile_mark(2, false, stream);
   int rc = check_launch("mfma_bwd_weight");
   if (rc) return rc;

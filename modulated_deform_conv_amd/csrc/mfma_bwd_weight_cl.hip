@@ -1,0 +1,203 @@
+// mfma_bwd_weight_cl.hip -- GEMM-2 (grad_weight) with CHANNELS-LAST gathers (fp32, gfx950).
+//
+// Same contraction as mfma_bwd_weight.hip (M = output channels, N = input channels of one tap,
+// K = pixels, split-K), but the column operand is sampled from the channels-last copy of the
+// input, xt[b][q][c] (see mfma_fwd_cl.hip for why: with NCHW every lane of a 3-D gather lands in
+// its own cache line; in xt a corner of 64 channels is one 256-byte segment).
+//
+//   * workgroup tile = (WR * MB * 32) output channels x 64 input channels; a thread owns
+//     (pixel kk of the 16-pixel chunk, channel quad cq): 2^ND 16-byte loads per chunk, blended
+//     into 4 values of the B slab [16 pixels][64 channels];
+//   * the tap table entry of (tap, pixel) holds 2^ND corner byte offsets into xt and 2^ND weights
+//     (mask, validity and load gating folded in); it is written by GEMM-1 (mfma_bwd_data.hip);
+//   * everything else (packed grad_out fragments, double-buffered slab, split-K partials and the
+//     reduction) is shared with the NCHW kernel.
+#include "mfma_kernels.hpp"
+#include "mfma_tile.hpp"
+
+namespace mdconv {
+
+namespace {
+
+// <WR, WC, MB, NBW>: WR x WC waves, each MB x NBW blocks of 32 x 32; WC * NBW * 32 == 64
+//   <2, 2, 1, 1>   64 x 64    C_out <= 64
+//   <2, 2, 2, 1>  128 x 64    C_out <= 128
+//   <4, 1, 2, 2>  256 x 64
+template <int ND, bool PADN, int WR, int WC, int MB, int NBW>
+__global__ __launch_bounds__(256) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims bd,
+                                                                 const float *__restrict__ xt,
+                                                                 const float *__restrict__ ga,
+                                                                 const int *__restrict__ table,
+                                                                 float *__restrict__ part) {
+  static_assert(WR * WC == 4 && WC * NBW * 32 == 64, "four waves, 64 input channels");
+  constexpr int NC = 1 << ND;
+  constexpr int BK = kBK;
+  constexpr int RM = WR * MB * 32, CN = 64;
+  constexpr int kPitch = CN + 1;
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BK * kPitch];
+
+  // blockIdx.x = (mtile * K + tap) * cblks + cblk ; blockIdx.y = split
+  int id = blockIdx.x;
+  const int cblk = id % bd.cblks; id /= bd.cblks;
+  const int tap = id % g.K;
+  const int mtile = id / g.K;
+  const int split = blockIdx.y;
+  const int c0 = cblk * CN;
+
+  const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wcn = wave % WC;
+  const int cq = tid & 15, kk = tid >> 4;   // channel quad of the tile, pixel within the chunk
+
+  const int pairs_total = bd.Np / 32;
+  const int p_begin = split * bd.pairs_per_split;
+  const int p_end = min(p_begin + bd.pairs_per_split, pairs_total);
+  const int t_begin = 2 * p_begin, t_end = 2 * p_end;   // chunk range (16 pixels each), even count
+
+  const rsrc_t r_xt = make_rsrc(xt, (size_t)g.B * g.S_i * g.C * sizeof(float));
+  const int slab_bytes = bd.mblks * 2 * 64 * 16;
+  const rsrc_t r_ga = make_rsrc(ga, (size_t)(bd.Np / 16) * slab_bytes);
+  const int entry_bytes = 2 * NC * 4;
+  const rsrc_t r_tab = make_rsrc(table + (size_t)tap * bd.Np * (2 * NC), (size_t)bd.Np * entry_bytes);
+  const int wo = mtile * RM + wr * MB * 32;   // first output channel of this wave
+  const int a_voff = ((wo / 32) * 2 * 64 + lane) * 16;
+  // rows beyond C_out are padding; with conv groups only the output channels of the groups that
+  // own this wave's input channels can receive a gradient (block-diagonal dense product)
+  bool m_active = wo < g.O;
+  if (g.G > 1) {
+    const int cw = c0 + wcn * NBW * 32;
+    const int o_lo = (min(cw, g.C - 1) / g.Cg) * g.Og;
+    const int o_hi = (min(cw + NBW * 32 - 1, g.C - 1) / g.Cg + 1) * g.Og;
+    m_active = m_active && wo < o_hi && wo + MB * 32 > o_lo;
+  }
+  const int t_voff = kk * entry_bytes;
+  const int c_voff = (min(c0, g.C - 64) + cq * 4) * 4;   // C is a multiple of 64
+
+  f32x16 acc[MB][NBW];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+
+  struct Tab { int off[NC]; float w[NC]; };
+  auto load_tab = [&](Tab &tb, int t) {
+    const int soff = t * 16 * entry_bytes;
+#pragma unroll
+    for (int h = 0; h < NC / 4; ++h) {
+      const float4 a = buf_load4(r_tab, t_voff + h * 16, soff);
+      tb.off[4 * h + 0] = __float_as_int(a.x); tb.off[4 * h + 1] = __float_as_int(a.y);
+      tb.off[4 * h + 2] = __float_as_int(a.z); tb.off[4 * h + 3] = __float_as_int(a.w);
+      const float4 b = buf_load4(r_tab, t_voff + NC * 4 + h * 16, soff);
+      tb.w[4 * h + 0] = b.x; tb.w[4 * h + 1] = b.y; tb.w[4 * h + 2] = b.z; tb.w[4 * h + 3] = b.w;
+    }
+  };
+  float4 rg[NC];
+  auto gather = [&](const Tab &tb) {
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) rg[ci] = buf_load4(r_xt, tb.off[ci] + c_voff, 0);
+  };
+  auto commit = [&](const Tab &tb, int t, float *Bb) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+      s.x = fmaf(tb.w[ci], rg[ci].x, s.x); s.y = fmaf(tb.w[ci], rg[ci].y, s.y);
+      s.z = fmaf(tb.w[ci], rg[ci].z, s.z); s.w = fmaf(tb.w[ci], rg[ci].w, s.w);
+    }
+    if (PADN && t * 16 + kk >= g.N) s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float *d = Bb + kk * kPitch + cq * 4;
+    d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
+  };
+  auto load_a = [&](float4 (&ra)[MB][2], int t) {
+    if (!m_active) return;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) ra[i][q] = buf_load4(r_ga, a_voff + (i * 2 + q) * 1024, t * slab_bytes);
+  };
+  auto mma = [&](const float4 (&ra)[MB][2], const float *Bbuf) {
+    if (!m_active) return;
+    const float *Bb = Bbuf + wcn * NBW * 32 + (lane & 31) + 4 * kh * kPitch;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float b[NBW];
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) b[n] = Bb[(8 * q + s) * kPitch + n * 32];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
+#pragma unroll
+          for (int n = 0; n < NBW; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[i][n], 0, 0, 0);
+        }
+      }
+  };
+
+  if (t_begin < t_end) {
+    const int t_last = t_end - 1;
+    Tab tabA, tabB;
+    float4 ra0[MB][2] = {}, ra1[MB][2] = {};
+    load_tab(tabA, t_begin);
+    load_tab(tabB, t_begin + 1);
+    load_a(ra0, t_begin);
+    gather(tabA);
+    for (int t = t_begin; t < t_end; t += 2) {
+      // ---- even chunk ----
+      commit(tabA, t, Bs);
+      __syncthreads();
+      load_a(ra1, t + 1);                   // A first: vmcnt retires in order (see mfma_fwd.hip)
+      gather(tabB);                         // chunk t+1
+      load_tab(tabA, min(t + 2, t_last));   // chunk t+2
+      __builtin_amdgcn_sched_barrier(0);
+      mma(ra0, Bs);
+      // ---- odd chunk ----
+      commit(tabB, t + 1, Bs + BK * kPitch);
+      __syncthreads();
+      load_a(ra0, min(t + 2, t_last));
+      gather(tabA);                         // chunk t+2 (or a harmless repeat at the end)
+      load_tab(tabB, min(t + 3, t_last));
+      __builtin_amdgcn_sched_barrier(0);
+      mma(ra1, Bs + BK * kPitch);
+    }
+  }
+
+  // partial tile -> part[split][tap][o][c]   (lanes 0-31 = 32 consecutive channels)
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) {
+    float *dst = part + ((size_t)(split * g.K + tap) * bd.OgpB) * bd.Cp + c0 + (wcn * NBW + n) * 32 + (lane & 31);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = wo + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        dst[(size_t)o * bd.Cp] = acc[mb][n][r];
+      }
+  }
+}
+
+}  // namespace
+
+int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt, const float *ga,
+                              const int *table, float *part, hipStream_t stream) {
+  const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
+  const bool padn = bd.Np != g.N;
+#define LAUNCH_CL(ND, PADN, WR, WC, MB, NBW)                                                    \
+  hipLaunchKernelGGL((mfma_bwd_weight_cl_kernel<ND, PADN, WR, WC, MB, NBW>), grid, dim3(256), 0, \
+                     stream, g, bd, xt, ga, table, part)
+#define LAUNCH_CL2(ND, PADN)                                                                    \
+  do {                                                                                          \
+    if (bd.wtile == 1) LAUNCH_CL(ND, PADN, 2, 2, 1, 1);                                         \
+    else if (bd.wtile == 2) LAUNCH_CL(ND, PADN, 2, 2, 2, 1);                                    \
+    else LAUNCH_CL(ND, PADN, 4, 1, 2, 2);                                                       \
+  } while (0)
+  if (g.nd == 2) { if (padn) LAUNCH_CL2(2, true); else LAUNCH_CL2(2, false); }
+  else { if (padn) LAUNCH_CL2(3, true); else LAUNCH_CL2(3, false); }
+#undef LAUNCH_CL2
+#undef LAUNCH_CL
+  return check_launch("mfma_bwd_weight_cl");
+}
+
+}  // namespace mdconv

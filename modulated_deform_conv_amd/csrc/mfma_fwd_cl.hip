@@ -278,12 +278,22 @@ bool fwd_channels_last(const Geom &g) {
 
 size_t fwd_cl_bytes(const Geom &g) { return (size_t)g.B * g.S_i * g.C * sizeof(float); }
 
+// GEMM-2 of the backward (mfma_bwd_weight_cl.hip) under the same conditions
+bool bwd_channels_last(const Geom &g) {
+  if (g.DG != 1 || g.C % kSlab) return false;
+  if (const char *e = getenv("MDCONV_BWD_CL")) return atoi(e) != 0;
+  return g.nd == 3;
+}
+
+int nchw_to_nhwc_f32(const Geom &g, const float *x, float *xt, hipStream_t stream) {
+  const dim3 tg((g.S_i + 31) / 32, g.C / 32, g.B);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, tg, dim3(256), 0, stream, g.C, g.S_i, x, xt);
+  return check_launch("nchw_to_nhwc");
+}
+
 int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
                         float *xt, hipStream_t stream) {
-  const dim3 tg((g.S_i + 31) / 32, g.C / 32, g.B);
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, tg, dim3(256), 0, stream, g.C, g.S_i,
-                     (const float *)t.input, xt);
-  int rc = check_launch("nchw_to_nhwc");
+  const int rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream);
   if (rc) return rc;
   if (g.nd == 2)
     return g.modulated ? launch_cl_tiles<2, true>(g, pd, t, wp, xt, stream)

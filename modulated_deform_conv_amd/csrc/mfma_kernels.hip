@@ -93,11 +93,15 @@ BwdDims bwd_dims(const Geom &g) {
   BwdDims bd;
   bd.Np = (g.N + 31) / 32 * 32;
   // 64 x 64 tiles (all four waves busy when C_out <= 64) were measured SLOWER than 256 x 32 tiles
-  // with idle waves at cfg4 (GEMM-2 5.4 -> 8 ms): the kernel is bound by the cache-line traffic
-  // of the 8-corner gathers, not by the matrix work, so the variant stays an experiment.
+  // with idle waves at cfg4 for the NCHW gathers (GEMM-2 5.4 -> 8 ms: bound by the cache-line
+  // traffic of the 8-corner gathers, not by the matrix work), so that variant stays an experiment.
+  // With channels-last gathers the tile is always 64 input channels wide.
+  bd.cl = bwd_channels_last(g) ? 1 : 0;
   bd.wtile = 0;
   if (const char *e = getenv("MDCONV_BW_TILE")) bd.wtile = atoi(e) == 1 && g.O <= 64 ? 1 : 0;
-  const int rm = bd.wtile ? 64 : 256, cn = bd.wtile ? 64 : 32;
+  if (bd.cl) bd.wtile = g.O <= 64 ? 1 : (g.O <= 128 ? 2 : 3);
+  const int rm = bd.cl ? (bd.wtile == 1 ? 64 : (bd.wtile == 2 ? 128 : 256)) : (bd.wtile ? 64 : 256);
+  const int cn = bd.cl ? 64 : (bd.wtile ? 64 : 32);
   bd.OgpB = (g.O + rm - 1) / rm * rm;
   bd.mblks = bd.OgpB / 32;
   bd.mtiles = bd.OgpB / rm;
@@ -126,6 +130,7 @@ BwdDims bwd_dims(const Geom &g) {
   bd.off_entries = off; off += align_up((size_t)g.B * g.DG * g.K * g.S_o * (nc / 2) * 16);
   bd.bias_tiles = (g.N + 32 * (4 / bd.waves_c) - 1) / (32 * (4 / bd.waves_c));
   bd.off_bias = off; off += align_up((size_t)bd.bias_tiles * g.O * sizeof(float));
+  bd.off_xt = off;   off += bd.cl ? align_up((size_t)g.B * g.S_i * g.C * sizeof(float)) : 0;
   bd.off_end = off;
   return bd;
 }
@@ -275,7 +280,9 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, stream);
   profile_mark(1, false, stream);
   if (rc) return rc;
-  if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, stream))) return rc;
+  float *xt = bd.cl ? (float *)(base + bd.off_xt) : nullptr;
+  if (bd.cl && (rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream))) return rc;
+  if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
   if (weights_final && (rc = record_weight_ready(stream))) return rc;
   if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, stream))) return rc;
   return col2im_f32(g, t, gcol, rowptr, entries, stream);

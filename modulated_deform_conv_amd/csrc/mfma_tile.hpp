@@ -71,7 +71,9 @@ __device__ __forceinline__ void buf_store4(rsrc_t r, int voff, int soff, float a
 // Dimensions / workspace layout of the MFMA backward (fp32, groups == 1).
 struct BwdDims {
   int Np;               // B*S_o rounded up to 32 (even number of 16-pixel chunks)
-  int wtile;            // GEMM-2 workgroup tile: 0 = 256(o) x 32(c), 1 = 64 x 64 (C_out <= 64)
+  int cl;               // GEMM-2 gathers from the channels-last input copy (mfma_bwd_weight_cl.hip)
+  int wtile;            // GEMM-2 workgroup tile: 0 = 256(o) x 32(c), 1 = 64 x 64 (C_out <= 64);
+                        // channels-last: 1 = 64 x 64, 2 = 128 x 64, 3 = 256 x 64
   int OgpB, mblks, mtiles;   // C_out rounded up to the tile rows; /32; / tile rows
   int Cp, cblks;        // C_in rounded up to the tile channels; / tile channels
   int splits, pairs_per_split;   // split-K of the grad_weight GEMM over pixel-chunk pairs
@@ -80,7 +82,7 @@ struct BwdDims {
   // workspace byte offsets
   int bias_tiles;       // pixel tiles of GEMM-1 = rows of the grad_bias partial sums
   size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
-      off_end;
+      off_xt, off_end;
 };
 BwdDims bwd_dims(const Geom &g);
 
@@ -102,7 +104,12 @@ size_t fwd_cl_bytes(const Geom &g);
 int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
                         float *xt, hipStream_t stream);
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
-                        const int *table, float *part, const float *bias_part, hipStream_t stream);
+                        const int *table, float *part, const float *bias_part, const float *xt,
+                        hipStream_t stream);
+int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt, const float *ga,
+                              const int *table, float *part, hipStream_t stream);
+bool bwd_channels_last(const Geom &g);
+int nchw_to_nhwc_f32(const Geom &g, const float *x, float *xt, hipStream_t stream);
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
