@@ -102,13 +102,16 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
 // straight-line code; QPQ == 0: any shape, runtime loops.
 constexpr int kTapGroup = 9;
 
-template <int ND, bool MOD, int WAVES_C, int QPQ>
+// CL: the drain gathers from the channels-last input copy xt[b][q][c] (mfma_fwd_cl.hip): a lane
+// fetches 4 consecutive channels of ONE corner of its pixel with a 16-byte load -- half the load
+// instructions of the paired NCHW loads and, in 3-D, a third of the cache lines.
+template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL>
 __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
     float *__restrict__ ga, float *__restrict__ bias_part, int *__restrict__ cnt,
-    int *__restrict__ table, int ntiles, int n_full, int n_tail) {
+    int *__restrict__ table, const float *__restrict__ xt, int ntiles, int n_full, int n_tail) {
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   const int bpd = per_block ? g.Cdg / 64 : nblk;   // 64-channel blocks per deformable group
   const int frag_bytes = 64 * 16;                      // one [lane][4] fragment
   const int chunk_bytes = bd.cblks_q * 2 * frag_bytes; // one ochunk of wq
-  const rsrc_t r_in = make_rsrc(input, (size_t)g.B * g.C * g.S_i * 4);
+  const rsrc_t r_in = make_rsrc(CL ? xt : input, (size_t)g.B * g.C * g.S_i * 4);
   const rsrc_t r_wq = make_rsrc(wq, (size_t)g.K * T_o * chunk_bytes);
   const rsrc_t r_gc = make_rsrc(gcol, (size_t)g.B * g.C * g.K * g.S_o * 4);
   const int a_lane = lane * 16;
@@ -262,12 +265,15 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   // sampling state of the tap being drained; before the first drain every gather / store goes
   // out of range and the parked accumulators are 0
   int voff[NP], gc_voff = kOob;
+  int voffc[NC];   // CL: byte offsets of the 2^ND corners of the lane's pixel in xt (+ 16 * kh)
   float w[NC], dw[ND][NC], mg = 0.f;
   float S[NC];
   float delta_n[ND], m_n = 1.f;   // raw offset / mask of the unit whose K loop is running
   f32x16 acc[MB], accp[MB];
 #pragma unroll
   for (int pi = 0; pi < NP; ++pi) voff[pi] = kOob;
+#pragma unroll
+  for (int ci = 0; ci < NC; ++ci) voffc[ci] = kOob;
 #pragma unroll
   for (int ci = 0; ci < NC; ++ci) { S[ci] = 0.f; w[ci] = 0.f; }
 #pragma unroll
@@ -333,6 +339,8 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
       voff[pi] = (pp.b * g.C * g.S_i + pidx[pi] + 4 * kh * g.S_i) * 4;
+      voffc[2 * pi] = (pp.b * g.S_i + pidx[pi]) * g.C * 4 + 16 * kh;
+      voffc[2 * pi + 1] = voffc[2 * pi] + g.C * 4;
       w[2 * pi] = px[pi];
       w[2 * pi + 1] = py[pi];
     }
@@ -355,18 +363,39 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   };
 
   // ---- drain batch q of the parked accumulators (channels cbase_p ..): gather, then consume ----
-  auto gather = [&](int q, int cbase_p, float2 (&v)[RB][NP]) {
+  // v: RB rows x 2^ND corner values.  NCHW: [row][pair] float2 (one 8-byte load per pair and
+  // row); channels-last: [quad of 4 rows][corner] float4 (one 16-byte load per corner and quad).
+  struct Batch { float f[RB * NC]; };
+  auto gather = [&](int q, int cbase_p, Batch &v) {
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
+    if (CL) {
 #pragma unroll
-    for (int rr = 0; rr < RB; ++rr) {
-      const int r = r0 + rr;
-      const int cu = cbase_p + mb * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh is in the voffset
-      const int cs = min(cu, g.C - 5) * g.S_i * 4;   // cu % 8 < 4, so C-5 is the last valid one
+      for (int gq = 0; gq < RB / 4; ++gq) {
+        const int cu4 = cbase_p + mb * 32 + 8 * ((r0 >> 2) + gq);   // + 4*kh is in the voffset
+        const int cs = min(cu4, g.C - 8) * 4;
 #pragma unroll
-      for (int pi = 0; pi < NP; ++pi) v[rr][pi] = buf_load2(r_in, voff[pi], cs);
+        for (int ci = 0; ci < NC; ++ci) {
+          const float4 x = buf_load4(r_in, voffc[ci], cs);
+          float *d = v.f + (gq * NC + ci) * 4;
+          d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const int r = r0 + rr;
+        const int cu = cbase_p + mb * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh is in the voffset
+        const int cs = min(cu, g.C - 5) * g.S_i * 4;   // cu % 8 < 4, so C-5 is the last valid one
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+          const float2 x = buf_load2(r_in, voff[pi], cs);
+          v.f[(rr * NP + pi) * 2] = x.x;
+          v.f[(rr * NP + pi) * 2 + 1] = x.y;
+        }
+      }
     }
   };
-  auto consume = [&](int q, int cbase_p, const float2 (&v)[RB][NP]) {
+  auto consume = [&](int q, int cbase_p, const Batch &v) {
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
     // grad_col[b][tap][pix][c]: rows r0+4g .. r0+4g+3 are 4 consecutive channels.  Dead lanes
     // and padded channels store to an out-of-range offset, which the bounds check drops.
@@ -382,9 +411,10 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     for (int rr = 0; rr < RB; ++rr) {
       const float gc = accp[mb][r0 + rr];
 #pragma unroll
-      for (int pi = 0; pi < NP; ++pi) {
-        S[2 * pi] = fmaf(gc, v[rr][pi].x, S[2 * pi]);
-        S[2 * pi + 1] = fmaf(gc, v[rr][pi].y, S[2 * pi + 1]);
+      for (int ci = 0; ci < NC; ++ci) {
+        // element ci of the corner pairs = corner ci (pair ci/2, first / second element)
+        const float x = CL ? v.f[((rr >> 2) * NC + ci) * 4 + (rr & 3)] : v.f[(rr * NP + (ci >> 1)) * 2 + (ci & 1)];
+        S[ci] = fmaf(gc, x, S[ci]);
       }
     }
 #pragma unroll
@@ -528,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
 
 #pragma unroll
     for (int q = 0; q < NBATCH; ++q) {
-      float2 v[RB][NP];
+      Batch v;
       // straight-line path: the A fragment of chunk t+3 is requested BEFORE the gathers, so only
       // the fragment of chunk t+4 (needed four chunks later) queues behind them
       if (QPQ > 0) quad_head(q * QPQ * 4);
@@ -571,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     const int cbase_p = (passp * WAVES_C + wc) * 64;
 #pragma unroll
     for (int q = 0; q < NBATCH; ++q) {
-      float2 v[RB][NP];
+      Batch v;
       gather(q, cbase_p, v);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -877,16 +907,16 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, float *ga, float *bias_part, int *cnt, int *table,
-                      hipStream_t stream) {
+                      const float *xt, hipStream_t stream) {
   // cnt: per-(image, deformable group, input pixel) counters (zeroed by csr_zero_f32), counted
   // by GEMM-1 (CSR pass 1)
-#define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
+#define LAUNCH_BD_(ND, MOD, WC, QPQ, CL)                                                        \
   do {                                                                                          \
     const int bnp = 32 * (4 / WC);                                                              \
     const int ntiles = (g.N + bnp - 1) / bnp;                                                   \
     const size_t lds = bwd_data_lds_bytes(g, bd);                                               \
     if (lds > 64 * 1024) {                                                                      \
-      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ>, \
+      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; } \
     }                                                                                           \
@@ -896,20 +926,27 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
     const int slots = num_cus() * per_cu;                                                       \
     const int n_full = ntiles / slots * slots;                                                  \
     const int n_tail = (int)std::min<int64_t>((int64_t)(ntiles - n_full) * g.K, slots);         \
-    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ>), dim3(n_full + n_tail),        \
+    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>), dim3(n_full + n_tail),    \
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
-                       (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, table, ntiles,    \
-                       n_full, n_tail);                                                         \
+                       (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, table, xt,        \
+                       ntiles, n_full, n_tail);                                                 \
+  } while (0)
+/* channels-last drain only where it pays (3-D) */                                                \
+#define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
+  do {                                                                                          \
+    if (ND == 3 && xt != nullptr) LAUNCH_BD_(ND, MOD, WC, QPQ, (ND == 3));                      \
+    else LAUNCH_BD_(ND, MOD, WC, QPQ, false);                                                   \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \
     const int nbatch = ND == 2 ? 4 : 8, nquads = bd.ochunks / 4;                                \
-    const int qpq = (g.G == 1 && nquads % nbatch == 0 && nquads / nbatch <= 2) ? nquads / nbatch : 0; \
+    /* straight-line K loop: 2-D only (the 3-D instances spill ~100 registers) */               \
+    const int qpq = (ND == 2 && g.G == 1 && nquads % nbatch == 0 && nquads / nbatch <= 2) ? nquads / nbatch : 0; \
     if (bd.waves_c == 4) {                                                                      \
-      if (qpq == 1) LAUNCH_BD(ND, MOD, 4, 1);                                                   \
-      else if (qpq == 2) LAUNCH_BD(ND, MOD, 4, 2);                                              \
+      if (ND == 2 && qpq == 1) LAUNCH_BD(ND, MOD, 4, (ND == 2 ? 1 : 0));                        \
+      else if (ND == 2 && qpq == 2) LAUNCH_BD(ND, MOD, 4, (ND == 2 ? 2 : 0));                   \
       else LAUNCH_BD(ND, MOD, 4, 0);                                                            \
     } else if (bd.waves_c == 2) LAUNCH_BD(ND, MOD, 2, 0);                                       \
     else LAUNCH_BD(ND, MOD, 1, 0);                                                              \
@@ -918,6 +955,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
   else { if (g.modulated) LAUNCH_BD2(3, true); else LAUNCH_BD2(3, false); }
 #undef LAUNCH_BD2
 #undef LAUNCH_BD
+#undef LAUNCH_BD_
   return check_launch("mfma_bwd_data");
 }
 

@@ -275,13 +275,14 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   int rc;
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
   if ((rc = csr_zero_f32(g, cnt, stream))) return rc;
-  profile_mark(1, true, stream);
   float *bias_part = g.with_bias ? (float *)(base + bd.off_bias) : nullptr;
-  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, stream);
-  profile_mark(1, false, stream);
-  if (rc) return rc;
+  // channels-last copy of the input for the 3-D gathers of GEMM-1's drain and of GEMM-2
   float *xt = bd.cl ? (float *)(base + bd.off_xt) : nullptr;
   if (bd.cl && (rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream))) return rc;
+  profile_mark(1, true, stream);
+  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, stream);
+  profile_mark(1, false, stream);
+  if (rc) return rc;
   if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
   if (weights_final && (rc = record_weight_ready(stream))) return rc;
   if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, stream))) return rc;

@@ -114,7 +114,7 @@ int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, float *ga, float *bias_part, int *cnt, int *table,
-                      hipStream_t stream);
+                      const float *xt, hipStream_t stream);
 int csr_zero_f32(const Geom &g, int *cnt, hipStream_t stream);
 int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
                   hipStream_t stream);
