@@ -20,7 +20,9 @@ GOLDEN_CASES = ["cfg1_dcn2d_c4_8x8_b1", "dcn2d_s2_g2_dg2", "mdcn2d_s2_g4_dg2", "
                 "mdcn2d_rect_params", "dcn3d_s2_g2", "mdcn3d_basic", "mfma_mdcn2d_c32_o48_9x10",
                 "mfma_dcn3d_c16_o16_5x6x5",
                 # conv groups + deformable groups on the MFMA backward
-                "mfma_dcn2d_g2_c32_o32", "mfma_mdcn2d_g8_dg2_c256_o32"]
+                "mfma_dcn2d_g2_c32_o32", "mfma_mdcn2d_g8_dg2_c256_o32",
+                # channels-last 3-D kernels
+                "cl_mdcn3d_g2_c128_o64_k2"]
 ONLY_NEW = "--new" in sys.argv   # write only fixtures that do not exist yet
 
 
