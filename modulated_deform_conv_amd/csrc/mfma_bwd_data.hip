@@ -876,6 +876,77 @@ __global__ __launch_bounds__(256) void col2im_gather_grouped_kernel(
   }
 }
 
+
+// Few channels (C_in = 64 or 128, one deformable group): with lanes = channel quads only C/4 lanes
+// of a wave would carry data, so a wave walks 64 / LPD runs side by side (lane = (run j, channel
+// quad r)), all of the same image; tile = 4 * (64 / LPD) runs of kRun targets.
+template <int ND, int LPD>
+__global__ __launch_bounds__(256) void col2im_gather_narrow_kernel(
+    Geom g, const float *__restrict__ gcol, const int *__restrict__ rowptr,
+    const int4 *__restrict__ entries, float *__restrict__ grad_input) {
+  constexpr int NP = 1 << (ND - 1);
+  constexpr int NQ = 64 / LPD, RUNS = 4 * NQ, QT = RUNS * kRun;   // runs per wave / tile, targets
+  constexpr int CW = LPD * 4;                                      // channels (== C_in)
+  constexpr int UB = LPD < 16 ? LPD : 16;
+  __shared__ float tile[CW * (QT + 1)];                            // [c][q]
+  const int qtiles = (g.S_i + QT - 1) / QT;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = bid / qtiles;
+  const int q0 = (bid - b * qtiles) * QT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane / LPD, r = lane % LPD;
+  const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * g.C, (size_t)g.K * g.S_o * g.C * 4);
+  const int *rp = rowptr + (int64_t)b * (g.S_i + 1);
+  const int4 *ent = entries + (int64_t)b * ((int64_t)g.K * g.S_o * NP);
+  const int qs = q0 + (wave * NQ + j) * kRun;
+  const int c_voff = r * 16;
+  float4 cur = make_float4(0.f, 0.f, 0.f, 0.f), nxt = cur;
+  for (int step = 0; step <= kRun; ++step) {
+    const int a = qs - 1 + step;
+    const bool on = a >= 0 && a < g.S_i;
+    const int e0 = on ? rp[a] : 0, e1 = on ? rp[a + 1] : 0;
+    for (int base = e0; __any(base < e1); base += LPD) {
+      const int cnt = max(0, min(LPD, e1 - base));
+      const int4 mine = (r < cnt) ? ent[base + r] : make_int4(0, 0, 0, 0);   // weights 0, row 0 beyond
+#pragma unroll
+      for (int u0 = 0; u0 < LPD; u0 += UB) {
+        float4 v[UB];
+        float wx[UB], wy[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int src = __shfl(mine.x, u0 + u, LPD);
+          wx[u] = __int_as_float(__shfl(mine.y, u0 + u, LPD));
+          wy[u] = __int_as_float(__shfl(mine.z, u0 + u, LPD));
+          v[u] = buf_load4(r_gc, src * g.C * 4 + c_voff, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          cur.x = fmaf(wx[u], v[u].x, cur.x); cur.y = fmaf(wx[u], v[u].y, cur.y);
+          cur.z = fmaf(wx[u], v[u].z, cur.z); cur.w = fmaf(wx[u], v[u].w, cur.w);
+          nxt.x = fmaf(wy[u], v[u].x, nxt.x); nxt.y = fmaf(wy[u], v[u].y, nxt.y);
+          nxt.z = fmaf(wy[u], v[u].z, nxt.z); nxt.w = fmaf(wy[u], v[u].w, nxt.w);
+        }
+      }
+    }
+    if (step > 0) {
+      float *tp = tile + (r * 4) * (QT + 1) + (a - q0);
+      tp[0] = cur.x; tp[QT + 1] = cur.y; tp[2 * (QT + 1)] = cur.z; tp[3 * (QT + 1)] = cur.w;
+    }
+    cur = nxt;
+    nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  // transpose out: rows of 32 consecutive q per channel (whole 128-byte lines)
+  for (int x = threadIdx.x; x < CW * (QT / 8); x += 256) {
+    const int c = x / (QT / 8), qs8 = (x % (QT / 8)) * 8;
+    float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q0 + qs8;
+    const float *src = tile + c * (QT + 1) + qs8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (q0 + qs8 + k < g.S_i) dst[k] = g.acc_data ? dst[k] + src[k] : src[k];
+  }
+}
+
 }  // namespace
 
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream) {
@@ -992,7 +1063,18 @@ int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *ro
 #define LAUNCH_GG(ND, LPD)                                                                      \
   hipLaunchKernelGGL((col2im_gather_grouped_kernel<ND, LPD>), grid, dim3(256), 0, stream, g,    \
                      gcol, rowptr, (const int4 *)entries, (float *)t.grad_input)
-  if (g.DG > 1 && g.Cdg == 64) {
+#define LAUNCH_NARROW(ND, LPD)                                                                  \
+  do {                                                                                          \
+    const int qt = 4 * (64 / LPD) * kRun;                                                       \
+    hipLaunchKernelGGL((col2im_gather_narrow_kernel<ND, LPD>), dim3(g.B * ((g.S_i + qt - 1) / qt)), \
+                       dim3(256), 0, stream, g, gcol, rowptr, (const int4 *)entries,            \
+                       (float *)t.grad_input);                                                  \
+  } while (0)
+  if (g.DG == 1 && g.C == 64) {
+    if (g.nd == 2) LAUNCH_NARROW(2, 16); else LAUNCH_NARROW(3, 16);
+  } else if (g.DG == 1 && g.C == 128) {
+    if (g.nd == 2) LAUNCH_NARROW(2, 32); else LAUNCH_NARROW(3, 32);
+  } else if (g.DG > 1 && g.Cdg == 64) {
     if (g.nd == 2) LAUNCH_GG(2, 16); else LAUNCH_GG(3, 16);
   } else if (g.DG > 1 && g.Cdg == 128) {
     if (g.nd == 2) LAUNCH_GG(2, 32); else LAUNCH_GG(3, 32);
@@ -1004,6 +1086,7 @@ int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *ro
                        (const int4 *)entries, (float *)t.grad_input);
   }
 #undef LAUNCH_GG
+#undef LAUNCH_NARROW
   return check_launch("col2im_gather");
 }
 
