@@ -272,7 +272,8 @@ int launch_cl_tiles(const Geom &g, const PackDims &pd, const Tensors &t, const f
 
 bool fwd_channels_last(const Geom &g) {
   if (g.DG != 1 || g.Cg % kSlab) return false;
-  if (const char *e = getenv("MDCONV_FWD_CL")) return atoi(e) != 0;
+  static const int env = getenv("MDCONV_FWD_CL") ? atoi(getenv("MDCONV_FWD_CL")) : -1;   // read once
+  if (env >= 0) return env != 0;
   return g.nd == 3;
 }
 
@@ -281,7 +282,8 @@ size_t fwd_cl_bytes(const Geom &g) { return (size_t)g.B * g.S_i * g.C * sizeof(f
 // GEMM-2 of the backward (mfma_bwd_weight_cl.hip) under the same conditions
 bool bwd_channels_last(const Geom &g) {
   if (g.DG != 1 || g.C % kSlab) return false;
-  if (const char *e = getenv("MDCONV_BWD_CL")) return atoi(e) != 0;
+  static const int env = getenv("MDCONV_BWD_CL") ? atoi(getenv("MDCONV_BWD_CL")) : -1;   // read once
+  if (env >= 0) return env != 0;
   return g.nd == 3;
 }
 

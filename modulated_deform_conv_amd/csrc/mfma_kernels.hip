@@ -98,7 +98,8 @@ BwdDims bwd_dims(const Geom &g) {
   // With channels-last gathers the tile is always 64 input channels wide.
   bd.cl = bwd_channels_last(g) ? 1 : 0;
   bd.wtile = 0;
-  if (const char *e = getenv("MDCONV_BW_TILE")) bd.wtile = atoi(e) == 1 && g.O <= 64 ? 1 : 0;
+  static const int bw_tile_env = getenv("MDCONV_BW_TILE") ? atoi(getenv("MDCONV_BW_TILE")) : 0;
+  if (bw_tile_env == 1 && g.O <= 64) bd.wtile = 1;
   if (bd.cl) bd.wtile = g.O <= 64 ? 1 : (g.O <= 128 ? 2 : 3);
   const int rm = bd.cl ? (bd.wtile == 1 ? 64 : (bd.wtile == 2 ? 128 : 256)) : (bd.wtile ? 64 : 256);
   const int cn = bd.cl ? 64 : (bd.wtile ? 64 : 32);
@@ -116,7 +117,6 @@ BwdDims bwd_dims(const Geom &g) {
   bd.splits = (pairs + bd.pairs_per_split - 1) / bd.pairs_per_split;
   bd.ochunks = (g.O + 63) / 64 * 4;   // K loop of GEMM-1 is unrolled 4x
   bd.waves_c = g.C > 128 ? 4 : (g.C > 64 ? 2 : 1);
-  if (const char *e = getenv("MDCONV_BD_WAVES_C")) bd.waves_c = atoi(e);   // experiments
   bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
   const int nc = 1 << g.nd;
   size_t off = 0;
