@@ -1007,7 +1007,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
 /* channels-last drain only where it pays (3-D) */                                                \
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
   do {                                                                                          \
-    if (ND == 3 && xt != nullptr) LAUNCH_BD_(ND, MOD, WC, QPQ, (ND == 3));                      \
+    if (xt != nullptr && (ND == 3 || QPQ == 0)) LAUNCH_BD_(ND, MOD, WC, QPQ, (ND == 3 || QPQ == 0)); \
     else LAUNCH_BD_(ND, MOD, WC, QPQ, false);                                                   \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \

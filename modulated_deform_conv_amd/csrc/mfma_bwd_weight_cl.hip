@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims
   const int slab_bytes = bd.mblks * 2 * 64 * 16;
   const rsrc_t r_ga = make_rsrc(ga, (size_t)(bd.Np / 16) * slab_bytes);
   const int entry_bytes = 2 * NC * 4;
-  const rsrc_t r_tab = make_rsrc(table + (size_t)tap * bd.Np * (2 * NC), (size_t)bd.Np * entry_bytes);
+  const int dg = c0 / g.Cdg;   // the 64-channel tile lies inside one deformable group
+  const rsrc_t r_tab = make_rsrc(table + (size_t)(dg * g.K + tap) * bd.Np * (2 * NC),
+                                 (size_t)bd.Np * entry_bytes);
   const int wo = mtile * RM + wr * MB * 32;   // first output channel of this wave
   const int a_voff = ((wo / 32) * 2 * 64 + lane) * 16;
   // rows beyond C_out are padding; with conv groups only the output channels of the groups that

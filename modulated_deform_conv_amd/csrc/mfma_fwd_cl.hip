@@ -281,10 +281,12 @@ size_t fwd_cl_bytes(const Geom &g) { return (size_t)g.B * g.S_i * g.C * sizeof(f
 
 // GEMM-2 of the backward (mfma_bwd_weight_cl.hip) under the same conditions
 bool bwd_channels_last(const Geom &g) {
-  if (g.DG != 1 || g.C % kSlab) return false;
+  if (g.C % kSlab || (g.DG != 1 && g.Cdg % kSlab)) return false;   // a 64-channel block = one group
   static const int env = getenv("MDCONV_BWD_CL") ? atoi(getenv("MDCONV_BWD_CL")) : -1;   // read once
   if (env >= 0) return env != 0;
-  return g.nd == 3;
+  // 3-D always; 2-D only where GEMM-1 is bound by its drain rather than by the matrix work: many
+  // conv groups leave one quad of K per tap (cfg3 shape: backward 2.58 -> 2.39 ms; cfg2: no gain)
+  return g.nd == 3 || g.G >= 8;
 }
 
 int nchw_to_nhwc_f32(const Geom &g, const float *x, float *xt, hipStream_t stream) {
