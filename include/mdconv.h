@@ -41,7 +41,8 @@ extern "C" {
 
 #define MDCONV_ABI_VERSION 1
 
-enum { MDCONV_F32 = 0, MDCONV_F16 = 1, MDCONV_F64 = 2 }; /* AT_DISPATCH_FLOATING_TYPES_AND_HALF */
+/* AT_DISPATCH_FLOATING_TYPES_AND_HALF (mdeformable_conv.cu:101) + bfloat16 */
+enum { MDCONV_F32 = 0, MDCONV_F16 = 1, MDCONV_F64 = 2, MDCONV_BF16 = 3 };
 
 enum {
   MDCONV_OK = 0,
@@ -59,7 +60,7 @@ enum { MDCONV_PATH_AUTO = 0, MDCONV_PATH_DIRECT = 1, MDCONV_PATH_MFMA = 2 };
 typedef struct mdconv_desc {
   int ndim;       /* 2 or 3 */
   int modulated;  /* 0 = DeformConv (DCNv1), 1 = ModulatedDeformConv (DCNv2) */
-  int dtype;      /* MDCONV_F32 / F16 / F64 -- element type of every tensor */
+  int dtype;      /* MDCONV_F32 / F16 / F64 / BF16 -- element type of every tensor */
   int batch;      /* B */
   int c_in;       /* C_in  */
   int c_out;      /* C_out */
@@ -88,6 +89,11 @@ size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward);
 int mdconv_set_path(int path);
 /* Path the last forward / backward call of this thread actually ran (MDCONV_PATH_DIRECT/MFMA). */
 int mdconv_last_path(void);
+/* Kernel family behind it: the shape-generic VALU kernels, the fp32 MFMA kernels (also used for
+ * 16-bit tensors through fp32 copies when the native kernels do not cover the shape), or the
+ * native fp16 / bf16 MFMA kernels. */
+enum { MDCONV_KERNELS_DIRECT = 1, MDCONV_KERNELS_F32 = 2, MDCONV_KERNELS_HP = 3 };
+int mdconv_last_kernels(void);
 
 /* Per-kernel timing for benchmarks: when enabled, the three MFMA GEMM kernels are bracketed by HIP
  * events ON THE CALLER'S STREAM.  After a stream/device synchronise, mdconv_profile_read() returns

@@ -18,7 +18,8 @@ import torch
 
 from . import _capi
 
-_DTYPES = {torch.float32: _capi.F32, torch.float16: _capi.F16, torch.float64: _capi.F64}
+_DTYPES = {torch.float32: _capi.F32, torch.float16: _capi.F16, torch.float64: _capi.F64,
+           torch.bfloat16: _capi.BF16}
 
 
 def _check_contig(**tensors):

@@ -9,12 +9,12 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDCONV_LIB") or os.path.join(HERE, "libmdconv_hip.so")
 
-F32, F16, F64 = 0, 1, 2
+F32, F16, F64, BF16 = 0, 1, 2, 3
 PATH_AUTO, PATH_DIRECT, PATH_MFMA = 0, 1, 2
 
 EXPORTS = (
     "mdconv_abi_version", "mdconv_last_error", "mdconv_out_size", "mdconv_workspace_bytes",
-    "mdconv_set_path", "mdconv_last_path",
+    "mdconv_set_path", "mdconv_last_path", "mdconv_last_kernels",
     "mdconv_profile_enable", "mdconv_profile_read", "mdconv_profile_reset",
     "mdconv_stream_wait_weight_ready", "mdconv_set_accumulate",
     "mdconv_deform_conv2d_forward", "mdconv_deform_conv2d_backward",
@@ -60,7 +60,8 @@ def lib():
         L.mdconv_set_accumulate.argtypes = [ctypes.c_int]
         L.mdconv_stream_wait_weight_ready.restype = ctypes.c_int
         L.mdconv_stream_wait_weight_ready.argtypes = [ctypes.c_void_p]
-        for name in EXPORTS[9:]:
+        L.mdconv_last_kernels.restype = ctypes.c_int
+        for name in EXPORTS[10:]:
             getattr(L, name).restype = ctypes.c_int
         if L.mdconv_abi_version() != 1:
             raise ImportError("libmdconv_hip.so ABI version mismatch")
@@ -81,6 +82,11 @@ def set_path(path):
 
 def last_path():
     return {0: "none", PATH_DIRECT: "direct", PATH_MFMA: "mfma"}[lib().mdconv_last_path()]
+
+
+def last_kernels():
+    """Kernel family of the last call: 'direct' | 'f32' (fp32 MFMA kernels) | 'hp' (native 16-bit)."""
+    return {0: "none", 1: "direct", 2: "f32", 3: "hp"}[lib().mdconv_last_kernels()]
 
 
 PROFILE_KERNELS = {0: "mfma_fwd_kernel", 1: "mfma_bwd_data_kernel", 2: "mfma_bwd_weight_kernel"}

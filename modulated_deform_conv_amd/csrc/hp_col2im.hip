@@ -1,0 +1,244 @@
+// hp_col2im.hip -- grad_input of the native 16-bit path: inverse scatter map + gather.
+//
+// Reference: the 4 / 8 atomics per sample of the gradient kernels (mdeformable_conv.cu:282-293,
+// mdeformable_conv3d.cu:341-379).  Here the data-dependent scatter is inverted once per call
+// (count [inside hp_bwd_kernel] -> scan -> fill; integer atomics only) into lists keyed by
+// (image, deformable group, input pixel): an ENTRY belongs to the first element ("anchor") of a
+// corner pair of one sample and carries (tap * S_o + output pixel, weight * mask on the anchor,
+// weight * mask on anchor + 1).  The gather then walks anchors: a group of LPD lanes (8 channels
+// each) follows one list, reads every 16-bit grad_col row [b][tap][pix][c] once per entry with
+// 16-byte loads, accumulates in fp32 (`cur` for the anchor, `nxt` for anchor + 1) and writes
+// grad_input [B, C, S_i] through an LDS transpose.  No floating-point atomics.
+#include "hp_kernels.hpp"
+
+namespace mdconv {
+
+namespace {
+
+int grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+__global__ __launch_bounds__(256) void hp_zero_int_kernel(int *__restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
+}
+
+// exclusive scan of cnt[seg][0..S_i) -> rowptr[seg][0..S_i], one workgroup per segment
+__global__ __launch_bounds__(256) void hp_csr_scan_kernel(int S_i, const int *__restrict__ cnt,
+                                                          int *__restrict__ rowptr) {
+  __shared__ int wsum[4];
+  __shared__ int carry;
+  const int seg = blockIdx.x;
+  const int *c = cnt + (int64_t)seg * S_i;
+  int *rp = rowptr + (int64_t)seg * (S_i + 1);
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < S_i; base += 256) {
+    const int i = base + threadIdx.x;
+    const int v = i < S_i ? c[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(x, d, 64);
+      if ((threadIdx.x & 63) >= d) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) woff += wsum[k];
+    const int excl = carry + woff + x - v;
+    if (i < S_i) rp[i] = excl;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = excl + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rp[S_i] = carry;
+}
+
+template <int ND, bool MOD, typename T>
+__global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, const typename T::Raw *__restrict__ offset,
+                                                          const typename T::Raw *__restrict__ mask,
+                                                          int *__restrict__ cursor,
+                                                          const int *__restrict__ rowptr,
+                                                          int4 *__restrict__ entries) {
+  constexpr int NP = 1 << (ND - 1);
+  const int64_t total = (int64_t)g.B * g.DG * g.K * g.S_o;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int pix = (int)(i % g.S_o);
+    const int tap = (int)((i / g.S_o) % g.K);
+    const int seg = (int)(i / g.S_o / g.K);   // b * DG + dg
+    int oc[ND], tcd[ND];
+    out_coords<ND>(g, pix, oc);
+    tap_coords<ND>(g, tap, tcd);
+    float delta[ND];
+    const int64_t ob = ((int64_t)seg * (ND * g.K) + ND * tap) * g.S_o + pix;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) delta[a] = T::ldf(offset + ob + (int64_t)a * g.S_o);
+    TapCoef<ND, float> tc;
+    make_tap<ND, float>(g, oc, tcd, delta, true, tc);
+    const float m = MOD ? T::ldf(mask + ((int64_t)seg * g.K + tap) * g.S_o + pix) : 1.f;
+    int aidx[NP];
+    float ax[NP], ay[NP], ux[NP], uy[NP];
+    make_pairs_f<ND, float>(g, tc, tc.wl, tc.wha, 1.f, aidx, ux, uy);   // which pairs exist (as counted)
+    make_pairs_f<ND, float>(g, tc, tc.wl, tc.wha, m, aidx, ax, ay);     // their weights, mask folded in
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+      if (ux[pi] != 0.f || uy[pi] != 0.f) {
+        const int q = aidx[pi];
+        const int pos = rowptr[(int64_t)seg * (g.S_i + 1) + q] + atomicAdd(cursor + (int64_t)seg * g.S_i + q, 1);
+        entries[(int64_t)seg * ((int64_t)g.K * g.S_o * NP) + pos] =
+            make_int4(tap * g.S_o + pix, __float_as_int(ax[pi]), __float_as_int(ay[pi]), 0);
+      }
+    }
+  }
+}
+
+constexpr int kRun = 8;   // targets per run
+
+// LPD lanes (8 channels each) follow one list; a wave walks 64 / LPD runs of kRun consecutive
+// anchors side by side; workgroup tile = 4 * (64 / LPD) runs.  Channel units of LPD * 8 channels
+// (one deformable group each when DG > 1) are processed one after the other.
+template <int ND, typename T, int LPD>
+__global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd,
+                                                        const typename T::Raw *__restrict__ gcol,
+                                                        const int *__restrict__ rowptr,
+                                                        const int4 *__restrict__ entries,
+                                                        typename T::Raw *__restrict__ grad_input) {
+  using Raw = typename T::Raw;
+  constexpr int NP = 1 << (ND - 1);
+  constexpr int NQ = 64 / LPD, RUNS = 4 * NQ, QT = RUNS * kRun;
+  constexpr int CW = LPD * 8;              // channels per unit
+  constexpr int UB = LPD < 8 ? LPD : 8;    // row loads in flight per step
+  constexpr int TP = QT + 2;               // LDS pitch (16-bit elements)
+  __shared__ Raw tile[CW * TP];
+  const int qtiles = (g.S_i + QT - 1) / QT;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = bid / qtiles;
+  const int q0 = (bid - b * qtiles) * QT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane / LPD, r = lane % LPD;
+  const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * hd.Cp, (size_t)g.K * g.S_o * hd.Cp * 2);
+  const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;   // channels that share one list
+  const int upd = (cseg + CW - 1) / CW;         // units per segment
+  const int units = g.DG * upd;
+  const int qs = q0 + (wave * NQ + j) * kRun;
+  for (int u = 0; u < units; ++u) {
+    const int dg = u / upd;
+    const int c_lo = dg * cseg + (u - dg * upd) * CW;          // first channel of the unit
+    const int c_end = min(dg * cseg + cseg, hd.Cp);            // end of the segment's channels
+    const int c8 = c_lo + r * 8;
+    const bool chan_on = c8 < c_end;
+    const int seg = b * g.DG + dg;
+    const int *rp = rowptr + (int64_t)seg * (g.S_i + 1);
+    const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o * NP);
+    const int c_voff = chan_on ? c8 * 2 : kHpOob;
+    float cur[8], nxt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cur[k] = nxt[k] = 0.f;
+    for (int step = 0; step <= kRun; ++step) {
+      const int a = qs - 1 + step;
+      const bool on = a >= 0 && a < g.S_i;
+      const int e0 = on ? rp[a] : 0, e1 = on ? rp[a + 1] : 0;
+      for (int base = e0; __any(base < e1); base += LPD) {
+        const int cnt = max(0, min(LPD, e1 - base));
+        const int4 mine = (r < cnt) ? ent[base + r] : make_int4(0, 0, 0, 0);   // weights 0, row 0 beyond
+#pragma unroll
+        for (int u0 = 0; u0 < LPD; u0 += UB) {
+          U4 v[UB];
+          float wx[UB], wy[UB];
+#pragma unroll
+          for (int k = 0; k < UB; ++k) {
+            const int src = __shfl(mine.x, u0 + k, LPD);
+            wx[k] = __int_as_float(__shfl(mine.y, u0 + k, LPD));
+            wy[k] = __int_as_float(__shfl(mine.z, u0 + k, LPD));
+            v[k] = buf_load4u(r_gc, src * hd.Cp * 2 + c_voff, 0);
+          }
+#pragma unroll
+          for (int k = 0; k < UB; ++k) {
+            mac8<T>(cur, v[k], wx[k]);
+            mac8<T>(nxt, v[k], wy[k]);
+          }
+        }
+      }
+      if (step > 0 && chan_on) {
+        Raw *tp = tile + (r * 8) * TP + (a - q0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) T::stf(tp + k * TP, cur[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { cur[k] = nxt[k]; nxt[k] = 0.f; }
+    }
+    __syncthreads();
+    // transpose out: consecutive threads -> consecutive q of one channel
+    for (int x = threadIdx.x; x < CW * QT; x += 256) {
+      const int cl = x / QT, ql = x - cl * QT;
+      const int c = c_lo + cl, q = q0 + ql;
+      if (c < min(c_end, g.C) && q < g.S_i) {
+        Raw *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q;
+        const float v = (float)tile[cl * TP + ql];
+        T::stf(dst, g.acc_data ? T::ldf(dst) + v : v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int ND, typename T>
+int launch_col2im(const Geom &g, const HpDims &hd, const Tensors &t, const void *gcol,
+                  const int *rowptr, const void *entries, hipStream_t stream) {
+  using Raw = typename T::Raw;
+  const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;
+  const int lanes = (cseg + 7) / 8;
+#define HP_C2I(LPD)                                                                              \
+  do {                                                                                           \
+    const int qt = 4 * (64 / LPD) * kRun;                                                        \
+    hipLaunchKernelGGL((hp_col2im_kernel<ND, T, LPD>), dim3(g.B * ((g.S_i + qt - 1) / qt)),      \
+                       dim3(256), 0, stream, g, hd, (const Raw *)gcol, rowptr,                   \
+                       (const int4 *)entries, (Raw *)t.grad_input);                              \
+  } while (0)
+  if (lanes <= 4) HP_C2I(4);
+  else if (lanes <= 8) HP_C2I(8);
+  else if (lanes <= 16) HP_C2I(16);
+  else if (lanes <= 32) HP_C2I(32);
+  else HP_C2I(64);
+#undef HP_C2I
+  return check_launch("hp_col2im");
+}
+
+}  // namespace
+
+int hp_csr_build(const Geom &g, int dtype, const Tensors &t, int *cnt, int *rowptr, void *entries,
+                 hipStream_t stream) {
+  const int64_t samples = (int64_t)g.B * g.DG * g.K * g.S_o;
+  const int64_t cnt_n = (int64_t)g.B * g.DG * g.S_i;
+  int rc;
+  hipLaunchKernelGGL(hp_csr_scan_kernel, dim3(g.B * g.DG), dim3(256), 0, stream, g.S_i, cnt, rowptr);
+  if ((rc = check_launch("hp_csr_scan"))) return rc;
+  hipLaunchKernelGGL(hp_zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
+  if ((rc = check_launch("hp_zero_cnt"))) return rc;
+#define HP_CSR(ND, MOD, T)                                                                        \
+  hipLaunchKernelGGL((hp_csr_fill_kernel<ND, MOD, T>), dim3(grid_for(samples)), dim3(256), 0, stream, g, \
+                     (const typename T::Raw *)t.offset, (const typename T::Raw *)t.mask, cnt, rowptr,    \
+                     (int4 *)entries)
+#define HP_CSR_T(T)                                                                               \
+  do {                                                                                            \
+    if (g.nd == 2) { if (g.modulated) HP_CSR(2, true, T); else HP_CSR(2, false, T); }             \
+    else { if (g.modulated) HP_CSR(3, true, T); else HP_CSR(3, false, T); }                       \
+  } while (0)
+  if (dtype == MDCONV_F16) HP_CSR_T(F16); else HP_CSR_T(BF16);
+#undef HP_CSR_T
+#undef HP_CSR
+  return check_launch("hp_csr_fill");
+}
+
+int hp_col2im(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *gcol,
+              const int *rowptr, const void *entries, hipStream_t stream) {
+  if (dtype == MDCONV_F16)
+    return g.nd == 2 ? launch_col2im<2, F16>(g, hd, t, gcol, rowptr, entries, stream)
+                     : launch_col2im<3, F16>(g, hd, t, gcol, rowptr, entries, stream);
+  return g.nd == 2 ? launch_col2im<2, BF16>(g, hd, t, gcol, rowptr, entries, stream)
+                   : launch_col2im<3, BF16>(g, hd, t, gcol, rowptr, entries, stream);
+}
+
+}  // namespace mdconv

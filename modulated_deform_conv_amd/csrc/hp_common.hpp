@@ -1,0 +1,148 @@
+// hp_common.hpp -- shared pieces of the native 16-bit (fp16 / bf16) kernels for gfx950.
+//
+// Half tensors never pass through fp32 copies (round 1 widened / narrowed every tensor): the
+// kernels read __half / bf16 operands directly, keep coordinates, interpolation weights and every
+// accumulator in fp32, and contract on v_mfma_f32_32x32x16_{f16,bf16} (16x the fp32 matrix
+// rate), which turns the whole op from matrix-bound into texture-path (gather) bound.  Design:
+//
+//   * xt[b][q][Cp] -- channels-last copy of the input in its own 16-bit type (Cp = C_in rounded
+//     up to 32, zero padded): one corner of 8 channels is ONE 16-byte load;
+//   * a lane owns (pixel = lane & 31, channel octet = lane >> 5), which is exactly the B-operand
+//     fragment of the 32x32x16 MFMA (N = pixel, K = 8 consecutive channels per half-wave): the
+//     interpolated column values go from the gather registers straight into the matrix core, no
+//     LDS round trip for the column operand at all;
+//   * corners outside the image are never read: their buffer offset is parked out of range and the
+//     hardware bounds check returns 0 (the reference's `if (h_low >= 0 ...)`,
+//     mdeformable_conv.cu:9-34) -- also for non-finite border pixels.
+#pragma once
+#include "mdconv_common.hpp"
+#include "mfma_tile.hpp"
+
+namespace mdconv {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32;
+struct U4 { u32 x, y, z, w; };   // 8 packed 16-bit elements
+
+constexpr int kHpOob = 0x7ffffff0;   // buffer offset beyond every num_records: loads 0, stores drop
+
+// 16-bit element types.  `Raw` = the in-memory type; everything is moved around as packed u32.
+struct F16 {
+  using Raw = _Float16;
+  static __device__ __forceinline__ float lo(u32 p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+  static __device__ __forceinline__ float hi(u32 p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+  static __device__ __forceinline__ u32 pack(float a, float b) {
+    const f16x2 v = {(_Float16)a, (_Float16)b};   // v_cvt_pk_f16_f32 (round to nearest even)
+    return __builtin_bit_cast(u32, v);
+  }
+  static __device__ __forceinline__ float ldf(const Raw *p) { return (float)*p; }
+  static __device__ __forceinline__ void stf(Raw *p, float v) { *p = (_Float16)v; }
+  // acc + w * element(p, HI): one v_fma_mix_f32 (fp16 source, fp32 weight and accumulator)
+  template <int HI> static __device__ __forceinline__ float mac(float acc, u32 p, float w) {
+    float r;
+    if (HI)
+      asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(w), "v"(acc));
+    else
+      asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(w), "v"(acc));
+    return r;
+  }
+  // acc + a.lo * b.lo + a.hi * b.hi in fp32 (v_dot2c_f32_f16)
+  static __device__ __forceinline__ float dot2(float acc, u32 a, u32 b) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), acc, false);
+  }
+  static __device__ __forceinline__ f32x16 mfma(const U4 &a, const U4 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+struct BF16 {
+  using Raw = __bf16;
+  static __device__ __forceinline__ float lo(u32 p) { return __builtin_bit_cast(float, p << 16); }
+  static __device__ __forceinline__ float hi(u32 p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+  static __device__ __forceinline__ u32 pack(float a, float b) {
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(u32, v);
+  }
+  static __device__ __forceinline__ float ldf(const Raw *p) { return (float)*p; }
+  static __device__ __forceinline__ void stf(Raw *p, float v) { *p = (__bf16)v; }
+  template <int HI> static __device__ __forceinline__ float mac(float acc, u32 p, float w) {
+    return fmaf(w, HI ? hi(p) : lo(p), acc);
+  }
+  static __device__ __forceinline__ float dot2(float acc, u32 a, u32 b) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+  }
+  static __device__ __forceinline__ f32x16 mfma(const U4 &a, const U4 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ U4 buf_load4u(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store4u(rsrc_t r, int voff, int soff, const U4 &v) {
+  typedef unsigned int u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
+// acc[j] += w * element j of the 8 packed values in v
+template <typename T> __device__ __forceinline__ void mac8(float (&acc)[8], const U4 &v, float w) {
+  acc[0] = T::template mac<0>(acc[0], v.x, w); acc[1] = T::template mac<1>(acc[1], v.x, w);
+  acc[2] = T::template mac<0>(acc[2], v.y, w); acc[3] = T::template mac<1>(acc[3], v.y, w);
+  acc[4] = T::template mac<0>(acc[4], v.z, w); acc[5] = T::template mac<1>(acc[5], v.z, w);
+  acc[6] = T::template mac<0>(acc[6], v.w, w); acc[7] = T::template mac<1>(acc[7], v.w, w);
+}
+template <typename T> __device__ __forceinline__ U4 pack8(const float (&a)[8]) {
+  U4 r;
+  r.x = T::pack(a[0], a[1]); r.y = T::pack(a[2], a[3]); r.z = T::pack(a[4], a[5]); r.w = T::pack(a[6], a[7]);
+  return r;
+}
+// s + sum over the 8 packed elements of a[j] * b[j] (fp32 accumulation).  NOTE: values that come
+// straight out of an MFMA must reach inline asm (mac8) only through compiler-visible instructions
+// such as these: hipcc does not pad the MFMA -> VALU read hazard for an asm statement.
+template <typename T> __device__ __forceinline__ float dot8(float s, const U4 &a, const U4 &b) {
+  s = T::dot2(s, a.x, b.x); s = T::dot2(s, a.y, b.y);
+  s = T::dot2(s, a.z, b.z); s = T::dot2(s, a.w, b.w);
+  return s;
+}
+
+// Per-(tap, pixel) sampling state for the channels-last gathers: element index of every corner
+// inside one image of xt (or -1: the reference does not read that corner) and its interpolation
+// weight (validity folded in; `bwd` selects the backward gating flavours of make_tap).
+template <int ND> struct HpCorners {
+  int idx[1 << ND];
+  float w[1 << ND];
+};
+template <int ND>
+__device__ __forceinline__ void hp_corners(const TapCoef<ND, float> &tc, HpCorners<ND> &hc) {
+#pragma unroll
+  for (int ci = 0; ci < (1 << ND); ++ci) {
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) ok = ok && (((ci >> (ND - 1 - a)) & 1) ? tc.vh[a] : tc.vl[a]);
+    hc.idx[ci] = ok ? corner_index<ND, float>(tc, ci) : -1;
+    hc.w[ci] = corner_weight<ND, float>(tc, ci);
+  }
+}
+
+// ---- dimensions / workspace of the 16-bit path ----
+struct HpDims {
+  int Cp;           // C_in rounded up to 32: channel pitch of xt and of the grad_col rows
+  int cblks;        // Cp / 32
+  int Op;           // C_out rounded up to 32
+  int oblks;        // Op / 32
+  int OpL;          // rows of the backward kernel's grad_out tile in LDS (>= Op)
+  // forward
+  int MB;           // output-channel blocks (of 32) per workgroup: 1, 2, 4 or 8
+  int oranges;      // workgroup rows along C_out = ceil(oblks / MB)
+  // backward
+  int nks;          // GEMM-1 k-steps (16 output channels each) per 32-channel block
+  int MB2;          // GEMM-2 output-channel blocks per 32-channel block
+  int waves;        // waves per workgroup of the fused backward kernel = cblks (<= 8)
+  int ranges;       // pixel ranges per tap (split-K of grad_weight)
+  int tiles_per_range;
+  int ntiles;       // 32-pixel tiles
+};
+
+}  // namespace mdconv

@@ -1,0 +1,224 @@
+// hp_host.hip -- dispatch, workspace layout and kernel sequence of the native 16-bit path.
+//
+// forward : pack weights -> channels-last input copy -> hp_fwd_kernel
+// backward: pack W^T -> channels-last input copy -> hp_bwd_kernel (GEMM-1 + coordinate gradients +
+//           grad_col + GEMM-2 with ONE gather pass, CSR counting) -> split-K reduce of grad_weight,
+//           grad_bias -> [weights-ready event] -> CSR scan + fill -> col2im gather
+// Calls whose channels-last copy would exceed 2 GiB (32-bit buffer offsets) are cut into batch
+// chunks; grad_weight accumulates across chunks.
+#include "hp_kernels.hpp"
+
+#include <stdlib.h>
+
+#include "mfma_kernels.hpp"
+
+namespace mdconv {
+
+namespace {
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int pow2_ceil(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+bool hp_enabled() {
+  static const int on = getenv("MDCONV_HP") ? atoi(getenv("MDCONV_HP")) : 1;
+  return on != 0;
+}
+
+size_t hp_chunk_limit() {
+  static size_t lim = 0;
+  if (!lim) {
+    lim = ((size_t)1 << 31) - (1 << 16);
+    const char *e = getenv("MDCONV_CHUNK_LIMIT_BYTES");
+    if (e && atoll(e) > 0 && (size_t)atoll(e) < lim) lim = (size_t)atoll(e);
+  }
+  return lim;
+}
+
+Geom chunk_geom(const Geom &g, int bc) {
+  Geom c = g;
+  c.B = bc;
+  c.N = bc * g.S_o;
+  return c;
+}
+
+struct FwdLayout { size_t off_xt, off_w, off_tab, total; };
+struct BwdLayout { size_t off_xt, off_w, off_tab, off_gcol, off_part, off_cnt, off_rowptr, off_entries, total; };
+
+// images per chunk: channels-last input copy (and one image's grad_col) below the limit
+int chunk_batch(const Geom &g, const HpDims &hd, bool backward) {
+  const size_t lim = hp_chunk_limit();
+  size_t per = (size_t)g.S_i * hd.Cp * 2;
+  const size_t per_out = (size_t)g.S_o * (backward ? hd.Op : g.O) * 2;
+  if (per_out > per) per = per_out;
+  if (per >= lim) return 0;
+  if (backward && (size_t)g.K * g.S_o * hd.Cp * 2 >= lim) return 0;   // one image's grad_col rows
+  int bc = (int)(lim / per);
+  return bc > g.B ? g.B : bc;
+}
+
+FwdLayout fwd_layout(const Geom &gc, const HpDims &hd) {
+  FwdLayout L;
+  size_t off = 0;
+  L.off_xt = off;  off += align_up((size_t)gc.B * gc.S_i * hd.Cp * 2);
+  L.off_w = off;   off += align_up((size_t)gc.K * (hd.Cp / 16) * hd.oblks * 1024);
+  L.off_tab = off; off += align_up((size_t)hd.oranges * (hd.Cp / 16 + 1) * sizeof(int2));
+  L.total = off;
+  return L;
+}
+
+BwdLayout bwd_layout(const Geom &gc, const HpDims &hd) {
+  BwdLayout L;
+  const int np = 1 << (gc.nd - 1);
+  size_t off = 0;
+  L.off_xt = off;   off += align_up((size_t)gc.B * gc.S_i * hd.Cp * 2);
+  L.off_w = off;    off += align_up((size_t)gc.K * hd.cblks * hd.nks * 1024);
+  L.off_tab = off;  off += align_up((size_t)hd.cblks * sizeof(int4));
+  L.off_gcol = off; off += align_up((size_t)gc.B * gc.K * gc.S_o * hd.Cp * 2);
+  L.off_part = off; off += align_up((size_t)gc.K * hd.ranges * hd.cblks * hd.MB2 * 4096);
+  L.off_cnt = off;  off += align_up((size_t)gc.B * gc.DG * gc.S_i * sizeof(int));
+  L.off_rowptr = off; off += align_up((size_t)gc.B * gc.DG * (gc.S_i + 1) * sizeof(int));
+  L.off_entries = off; off += align_up((size_t)gc.B * gc.DG * gc.K * gc.S_o * np * 16);
+  L.total = off;
+  return L;
+}
+
+}  // namespace
+
+int num_cus();   // mfma_bwd_data.hip
+
+HpDims hp_dims(const Geom &g) {
+  HpDims hd;
+  hd.Cp = (g.C + 31) / 32 * 32;
+  hd.cblks = hd.Cp / 32;
+  hd.Op = (g.O + 31) / 32 * 32;
+  hd.oblks = hd.Op / 32;
+  hd.MB = hd.oblks >= 5 ? 8 : (hd.oblks >= 3 ? 4 : hd.oblks);
+  hd.oranges = (hd.oblks + hd.MB - 1) / hd.MB;
+  // backward: widest output-channel range (32-aligned) any 32-channel block needs
+  int span = 32, base_max = 0;
+  for (int cblk = 0; cblk < hd.cblks; ++cblk) {
+    const int c_lo = cblk * 32 < g.C ? cblk * 32 : g.C - 1;
+    const int c_hi = cblk * 32 + 31 < g.C ? cblk * 32 + 31 : g.C - 1;
+    const int o_lo = (c_lo / g.Cg) * g.Og, o_hi = (c_hi / g.Cg + 1) * g.Og;
+    const int base = o_lo / 32 * 32;
+    const int s = (o_hi - base + 31) / 32 * 32;
+    if (s > span) span = s;
+    if (base > base_max) base_max = base;
+  }
+  hd.MB2 = pow2_ceil(span / 32);
+  hd.nks = hd.MB2 * 2;
+  hd.OpL = base_max + 32 * hd.MB2 > hd.Op ? base_max + 32 * hd.MB2 : hd.Op;
+  hd.waves = pow2_ceil(hd.cblks);
+  hd.ntiles = (g.N + 31) / 32;
+  // pixel ranges per tap: about one dispatch round of workgroups (2 four-wave workgroups per CU)
+  const int slots = num_cus() * (hd.waves >= 8 ? 1 : 2 * (4 / hd.waves));
+  int ranges = slots / g.K;
+  if (ranges < 1) ranges = 1;
+  if (ranges > hd.ntiles) ranges = hd.ntiles;
+  hd.tiles_per_range = (hd.ntiles + ranges - 1) / ranges;
+  hd.ranges = (hd.ntiles + hd.tiles_per_range - 1) / hd.tiles_per_range;
+  return hd;
+}
+
+bool hp_supported(const Geom &g, int dtype, bool backward) {
+  if (!hp_enabled()) return false;
+  if (dtype != MDCONV_F16 && dtype != MDCONV_BF16) return false;
+  if (g.DG > 1 && g.Cdg % (backward ? 32 : 16)) return false;
+  const HpDims hd = hp_dims(g);
+  if (backward) {
+    if (hd.cblks > 8 || hd.MB2 > 8) return false;   // one workgroup covers all input channels
+    if (g.in_sz[g.nd - 1] < 2) return false;        // pair-keyed scatter lists
+  }
+  return chunk_batch(g, hd, backward) > 0;
+}
+
+size_t hp_workspace_bytes(const Geom &g, int dtype, bool backward) {
+  HpDims hd = hp_dims(g);
+  const int bc = chunk_batch(g, hd, backward);
+  if (bc <= 0) return 0;
+  const Geom gc = chunk_geom(g, bc);
+  hd = hp_dims(gc);
+  return backward ? bwd_layout(gc, hd).total : fwd_layout(gc, hd).total;
+}
+
+int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  const int Bc = chunk_batch(g, hp_dims(g), false);
+  if (Bc <= 0) { set_error("hp_forward: no plan"); return MDCONV_EUNSUPPORTED; }
+  const Geom g0 = chunk_geom(g, Bc);
+  const HpDims hd0 = hp_dims(g0);
+  const FwdLayout L = fwd_layout(g0, hd0);
+  char *base = (char *)ws;
+  const int nc_off = g.DG * g.nd * g.K, nc_m = g.DG * g.K;
+  int rc;
+  if ((rc = hp_pack_fwd_weights(g0, hd0, dtype, t.weight, base + L.off_w, (int2 *)(base + L.off_tab), stream)))
+    return rc;
+  for (int b0 = 0; b0 < g.B; b0 += Bc) {
+    const int bc = g.B - b0 < Bc ? g.B - b0 : Bc;
+    const Geom gc = chunk_geom(g, bc);
+    const HpDims hd = hp_dims(gc);
+    Tensors tc = t;
+    tc.input = (const char *)t.input + (size_t)b0 * g.C * g.S_i * 2;
+    tc.offset = (const char *)t.offset + (size_t)b0 * nc_off * g.S_o * 2;
+    tc.mask = t.mask ? (const char *)t.mask + (size_t)b0 * nc_m * g.S_o * 2 : nullptr;
+    tc.output = (char *)t.output + (size_t)b0 * g.O * g.S_o * 2;
+    if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
+    profile_mark(0, true, stream);
+    rc = hp_forward_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+                           (const int2 *)(base + L.off_tab), stream);
+    profile_mark(0, false, stream);
+    if (rc) return rc;
+  }
+  return MDCONV_OK;
+}
+
+int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  const int Bc = chunk_batch(g, hp_dims(g), true);
+  if (Bc <= 0) { set_error("hp_backward: no plan"); return MDCONV_EUNSUPPORTED; }
+  const Geom g0 = chunk_geom(g, Bc);
+  const HpDims hd0 = hp_dims(g0);
+  const BwdLayout L = bwd_layout(g0, hd0);
+  char *base = (char *)ws;
+  const int nc_off = g.DG * g.nd * g.K, nc_m = g.DG * g.K;
+  int rc;
+  if ((rc = hp_pack_bwd_weights(g0, hd0, dtype, t.weight, base + L.off_w, (int4 *)(base + L.off_tab), stream)))
+    return rc;
+  if (g.with_bias && (rc = hp_grad_bias(g, dtype, t.grad_output, t.grad_bias, stream))) return rc;
+  for (int b0 = 0; b0 < g.B; b0 += Bc) {
+    const int bc = g.B - b0 < Bc ? g.B - b0 : Bc;
+    Geom gc = chunk_geom(g, bc);
+    gc.acc_w = b0 > 0 ? 1 : g.acc_w;
+    const HpDims hd = hp_dims(gc);
+    Tensors tc = t;
+    tc.input = (const char *)t.input + (size_t)b0 * g.C * g.S_i * 2;
+    tc.offset = (const char *)t.offset + (size_t)b0 * nc_off * g.S_o * 2;
+    tc.mask = t.mask ? (const char *)t.mask + (size_t)b0 * nc_m * g.S_o * 2 : nullptr;
+    tc.grad_output = (const char *)t.grad_output + (size_t)b0 * g.O * g.S_o * 2;
+    tc.grad_input = (char *)t.grad_input + (size_t)b0 * g.C * g.S_i * 2;
+    tc.grad_offset = (char *)t.grad_offset + (size_t)b0 * nc_off * g.S_o * 2;
+    tc.grad_mask = t.grad_mask ? (char *)t.grad_mask + (size_t)b0 * nc_m * g.S_o * 2 : nullptr;
+    int *cnt = (int *)(base + L.off_cnt), *rowptr = (int *)(base + L.off_rowptr);
+    if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
+    if ((rc = csr_zero_f32(gc, cnt, stream))) return rc;
+    profile_mark(1, true, stream);
+    rc = hp_backward_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+                            (const int4 *)(base + L.off_tab), base + L.off_gcol,
+                            (float *)(base + L.off_part), cnt, stream);
+    profile_mark(1, false, stream);
+    if (rc) return rc;
+    if ((rc = hp_reduce_grad_weight(gc, hd, dtype, (const float *)(base + L.off_part),
+                                    (const int4 *)(base + L.off_tab), t.grad_weight, stream)))
+      return rc;
+    if (b0 + bc >= g.B && (rc = record_weight_ready(stream))) return rc;
+    if ((rc = hp_csr_build(gc, dtype, tc, cnt, rowptr, base + L.off_entries, stream))) return rc;
+    if ((rc = hp_col2im(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, stream)))
+      return rc;
+  }
+  return MDCONV_OK;
+}
+
+}  // namespace mdconv

@@ -1,0 +1,40 @@
+// hp_kernels.hpp -- entry points of the native 16-bit (fp16 / bf16) path (hp_*.hip).
+#pragma once
+#include "hp_common.hpp"
+
+namespace mdconv {
+
+bool hp_supported(const Geom &g, int dtype, bool backward);
+size_t hp_workspace_bytes(const Geom &g, int dtype, bool backward);
+int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
+int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
+
+HpDims hp_dims(const Geom &g);
+
+// hp_prep.hip
+int hp_nchw_to_nhwc(const Geom &g, const HpDims &hd, const void *x, void *xt, hipStream_t stream);
+int hp_pack_fwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *w, void *wpf,
+                        int2 *ctab, hipStream_t stream);
+int hp_pack_bwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *w, void *wpb,
+                        int4 *btab, hipStream_t stream);
+int hp_reduce_grad_weight(const Geom &g, const HpDims &hd, int dtype, const float *part,
+                          const int4 *btab, void *grad_weight, hipStream_t stream);
+int hp_grad_bias(const Geom &g, int dtype, const void *grad_output, void *grad_bias,
+                 hipStream_t stream);
+
+// hp_fwd.hip
+int hp_forward_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
+                      const void *wpf, const int2 *ctab, hipStream_t stream);
+
+// hp_bwd.hip: GEMM-1 + coordinate gradients + grad_col + GEMM-2, one gather pass
+int hp_backward_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
+                       const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
+                       hipStream_t stream);
+
+// hp_col2im.hip: inverse scatter map (count inside hp_bwd) + gather
+int hp_csr_build(const Geom &g, int dtype, const Tensors &t, int *cnt, int *rowptr, void *entries,
+                 hipStream_t stream);
+int hp_col2im(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *gcol,
+              const int *rowptr, const void *entries, hipStream_t stream);
+
+}  // namespace mdconv

@@ -1,0 +1,243 @@
+// hp_prep.hip -- layout passes of the native 16-bit path: channels-last input copy, MFMA-fragment
+// weight packing (forward and backward), split-K reduction of grad_weight, grad_bias.
+#include "hp_kernels.hpp"
+
+namespace mdconv {
+
+namespace {
+
+int grid_for(int64_t total, int cap = 8192) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+// xt[b][q][Cp] = x[b][c][q] (0 for c >= C): 64 x 64 tiles through LDS, 16-byte stores.
+// Element type agnostic (moves 16-bit words).
+__global__ __launch_bounds__(256) void hp_nchw_to_nhwc_kernel(int C, int Cp, int S,
+                                                              const unsigned short *__restrict__ x,
+                                                              unsigned short *__restrict__ xt) {
+  __shared__ unsigned short t[64][66];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, q0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, q = q0 + tx;
+    t[r][tx] = (c < C && q < S) ? x[((size_t)b * C + c) * S + q] : (unsigned short)0;
+  }
+  __syncthreads();
+  for (int item = threadIdx.x; item < 64 * 8; item += 256) {
+    const int ql = item >> 3, oct = item & 7;
+    const int q = q0 + ql, c = c0 + oct * 8;
+    if (q < S && c < Cp) {
+      U4 v;
+      v.x = t[oct * 8 + 0][ql] | ((u32)t[oct * 8 + 1][ql] << 16);
+      v.y = t[oct * 8 + 2][ql] | ((u32)t[oct * 8 + 3][ql] << 16);
+      v.z = t[oct * 8 + 4][ql] | ((u32)t[oct * 8 + 5][ql] << 16);
+      v.w = t[oct * 8 + 6][ql] | ((u32)t[oct * 8 + 7][ql] << 16);
+      *reinterpret_cast<U4 *>(xt + ((size_t)b * S + q) * Cp + c) = v;
+    }
+  }
+}
+
+// forward A operand: wpf[tap][chunk][oblk][lane][8] = W[o = oblk*32 + (lane&31)]
+//                                                      [c = chunk*16 + 8*(lane>>5) + j][tap]
+// dense block-diagonal over conv groups (0 where o and c belong to different groups, or padding).
+__global__ __launch_bounds__(256) void hp_pack_fwd_kernel(Geom g, HpDims hd,
+                                                          const unsigned short *__restrict__ w,
+                                                          U4 *__restrict__ wpf) {
+  const int nchunks = hd.Cp / 16;
+  const int64_t total = (int64_t)g.K * nchunks * hd.oblks * 64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int oblk = (int)(r % hd.oblks); r /= hd.oblks;
+    const int chunk = (int)(r % nchunks);
+    const int tap = (int)(r / nchunks);
+    const int o = oblk * 32 + (lane & 31);
+    const int cb = chunk * 16 + 8 * (lane >> 5);
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb + j;
+      e[j] = (o < g.O && c < g.C && o / g.Og == c / g.Cg)
+                 ? w[((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap] : (unsigned short)0;
+    }
+    U4 v;
+    v.x = e[0] | ((u32)e[1] << 16); v.y = e[2] | ((u32)e[3] << 16);
+    v.z = e[4] | ((u32)e[5] << 16); v.w = e[6] | ((u32)e[7] << 16);
+    wpf[i] = v;
+  }
+}
+
+// per workgroup row (`orange`) and 16-channel chunk: the range of the row's output-channel blocks
+// that can be non-zero (relative to the row's first block); entry [nchunks] = the row's chunk range
+__global__ void hp_ctab_kernel(Geom g, HpDims hd, int2 *__restrict__ ctab) {
+  const int nchunks = hd.Cp / 16;
+  for (int orange = threadIdx.x; orange < hd.oranges; orange += blockDim.x) {
+    int2 *ct = ctab + orange * (nchunks + 1);
+    const int b_lo = orange * hd.MB, b_hi = min(b_lo + hd.MB, hd.oblks) - 1;
+    int ch_lo = nchunks, ch_hi = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      int lo = 0, n = 0;
+      if (ch * 16 < g.C) {
+        const int g_lo = (ch * 16) / g.Cg, g_hi = min(ch * 16 + 15, g.C - 1) / g.Cg;
+        const int ob_lo = max((g_lo * g.Og) / 32, b_lo);
+        const int ob_hi = min(((g_hi + 1) * g.Og - 1) / 32, b_hi);
+        if (ob_hi >= ob_lo) {
+          lo = ob_lo - b_lo;
+          n = ob_hi - ob_lo + 1;
+          ch_lo = min(ch_lo, ch);
+          ch_hi = max(ch_hi, ch + 1);
+        }
+      }
+      ct[ch] = make_int2(lo, n);
+    }
+    ct[nchunks] = make_int2(ch_lo, ch_hi);
+  }
+}
+
+// channel of MFMA row i of the backward A operand: a lane of the 32x32 accumulator then owns 16
+// CONSECUTIVE channels (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)  ->  channel 16*(lane>>5) + reg)
+__host__ __device__ inline int hp_sigma(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
+
+// backward A operand (W^T): wpb[tap][cblk][ks][lane][8] = W[o = o_base(cblk) + ks*16 + 8*(lane>>5) + j]
+//                                                           [c = cblk*32 + sigma(lane&31)][tap]
+__global__ __launch_bounds__(256) void hp_pack_bwd_kernel(Geom g, HpDims hd, const int4 *__restrict__ btab,
+                                                          const unsigned short *__restrict__ w,
+                                                          U4 *__restrict__ wpb) {
+  const int64_t total = (int64_t)g.K * hd.cblks * hd.nks * 64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int ks = (int)(r % hd.nks); r /= hd.nks;
+    const int cblk = (int)(r % hd.cblks);
+    const int tap = (int)(r / hd.cblks);
+    const int c = cblk * 32 + hp_sigma(lane & 31);
+    const int ob = btab[cblk].x + ks * 16 + 8 * (lane >> 5);
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int o = ob + j;
+      e[j] = (o < g.O && c < g.C && o / g.Og == c / g.Cg)
+                 ? w[((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap] : (unsigned short)0;
+    }
+    U4 v;
+    v.x = e[0] | ((u32)e[1] << 16); v.y = e[2] | ((u32)e[3] << 16);
+    v.z = e[4] | ((u32)e[5] << 16); v.w = e[6] | ((u32)e[7] << 16);
+    wpb[i] = v;
+  }
+}
+
+// per 32-channel block: first output channel (32-aligned) of the groups its channels belong to
+__global__ void hp_btab_kernel(Geom g, HpDims hd, int4 *__restrict__ btab) {
+  for (int cblk = threadIdx.x; cblk < hd.cblks; cblk += blockDim.x) {
+    const int c_lo = min(cblk * 32, g.C - 1), c_hi = min(cblk * 32 + 31, g.C - 1);
+    const int o_lo = (c_lo / g.Cg) * g.Og, o_hi = (c_hi / g.Cg + 1) * g.Og;
+    const int base = o_lo / 32 * 32;
+    btab[cblk] = make_int4(base, (o_hi - base + 31) / 32, 0, 0);
+  }
+}
+
+// grad_weight[o][c][tap] (+)= sum over the pixel ranges of part[tap][range][cblk][ob][lane][16]
+// (the 32x32 fp32 accumulator blocks of the fused backward kernel, D[i = o][j = c])
+template <typename T>
+__global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, const int4 *__restrict__ btab,
+                                                           const float *__restrict__ part,
+                                                           typename T::Raw *__restrict__ gw) {
+  const int64_t total = (int64_t)g.K * hd.cblks * hd.MB2 * 1024;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i;
+    const int reg = (int)(r & 15); r >>= 4;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int ob = (int)(r % hd.MB2); r /= hd.MB2;
+    const int cblk = (int)(r % hd.cblks);
+    const int tap = (int)(r / hd.cblks);
+    const int o = btab[cblk].x + ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    const int c = cblk * 32 + (lane & 31);
+    if (o < g.O && c < g.C && o / g.Og == c / g.Cg) {
+      const int64_t per_range = (int64_t)hd.cblks * hd.MB2 * 1024;
+      const float *p = part + ((int64_t)tap * hd.ranges) * per_range + ((int64_t)cblk * hd.MB2 + ob) * 1024 +
+                       lane * 16 + reg;
+      float s = 0.f;
+      for (int k = 0; k < hd.ranges; ++k) s += p[(int64_t)k * per_range];
+      typename T::Raw *dst = gw + ((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap;
+      T::stf(dst, g.acc_w ? T::ldf(dst) + s : s);
+    }
+  }
+}
+
+// grad_bias[o] (+)= sum over (b, pix) of grad_out[b][o][pix]; one workgroup per output channel
+template <typename T>
+__global__ __launch_bounds__(256) void hp_grad_bias_kernel(Geom g, const typename T::Raw *__restrict__ go,
+                                                           typename T::Raw *__restrict__ gb) {
+  __shared__ float red[256];
+  const int o = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < g.B; ++b) {
+    const typename T::Raw *src = go + ((int64_t)b * g.O + o) * g.S_o;
+    for (int i = threadIdx.x; i < g.S_o; i += 256) s += T::ldf(src + i);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) T::stf(gb + o, g.acc_w ? T::ldf(gb + o) + red[0] : red[0]);
+}
+
+}  // namespace
+
+int hp_nchw_to_nhwc(const Geom &g, const HpDims &hd, const void *x, void *xt, hipStream_t stream) {
+  const dim3 grid((g.S_i + 63) / 64, (hd.Cp + 63) / 64, g.B);
+  hipLaunchKernelGGL(hp_nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
+                     (const unsigned short *)x, (unsigned short *)xt);
+  return check_launch("hp_nchw_to_nhwc");
+}
+
+int hp_pack_fwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *w, void *wpf,
+                        int2 *ctab, hipStream_t stream) {
+  const int64_t total = (int64_t)g.K * (hd.Cp / 16) * hd.oblks * 64;
+  hipLaunchKernelGGL(hp_pack_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, hd,
+                     (const unsigned short *)w, (U4 *)wpf);
+  int rc = check_launch("hp_pack_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(hp_ctab_kernel, dim3(1), dim3(64), 0, stream, g, hd, ctab);
+  return check_launch("hp_ctab");
+}
+
+int hp_pack_bwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *w, void *wpb,
+                        int4 *btab, hipStream_t stream) {
+  hipLaunchKernelGGL(hp_btab_kernel, dim3(1), dim3(64), 0, stream, g, hd, btab);
+  int rc = check_launch("hp_btab");
+  if (rc) return rc;
+  const int64_t total = (int64_t)g.K * hd.cblks * hd.nks * 64;
+  hipLaunchKernelGGL(hp_pack_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, hd, btab,
+                     (const unsigned short *)w, (U4 *)wpb);
+  return check_launch("hp_pack_bwd");
+}
+
+int hp_reduce_grad_weight(const Geom &g, const HpDims &hd, int dtype, const float *part,
+                          const int4 *btab, void *grad_weight, hipStream_t stream) {
+  const int64_t total = (int64_t)g.K * hd.cblks * hd.MB2 * 1024;
+  if (dtype == MDCONV_F16)
+    hipLaunchKernelGGL((hp_reduce_gw_kernel<F16>), dim3(grid_for(total)), dim3(256), 0, stream, g, hd,
+                       btab, part, (_Float16 *)grad_weight);
+  else
+    hipLaunchKernelGGL((hp_reduce_gw_kernel<BF16>), dim3(grid_for(total)), dim3(256), 0, stream, g, hd,
+                       btab, part, (__bf16 *)grad_weight);
+  return check_launch("hp_reduce_gw");
+}
+
+int hp_grad_bias(const Geom &g, int dtype, const void *grad_output, void *grad_bias,
+                 hipStream_t stream) {
+  if (dtype == MDCONV_F16)
+    hipLaunchKernelGGL((hp_grad_bias_kernel<F16>), dim3(g.O), dim3(256), 0, stream, g,
+                       (const _Float16 *)grad_output, (_Float16 *)grad_bias);
+  else
+    hipLaunchKernelGGL((hp_grad_bias_kernel<BF16>), dim3(g.O), dim3(256), 0, stream, g,
+                       (const __bf16 *)grad_output, (__bf16 *)grad_bias);
+  return check_launch("hp_grad_bias");
+}
+
+}  // namespace mdconv

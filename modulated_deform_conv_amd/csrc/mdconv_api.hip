@@ -8,12 +8,14 @@
 #include <string.h>
 
 #include "mdconv_common.hpp"
+#include "hp_kernels.hpp"
 #include "mfma_kernels.hpp"
 
 namespace mdconv {
 
 static thread_local char g_err[512] = "";
 static thread_local int g_last_path = 0;
+static thread_local int g_last_kernels = 0;
 static thread_local int g_accumulate = 1;
 // "grad_weight / grad_bias are final" event of the last backward of this thread
 static thread_local hipEvent_t g_wready = nullptr;
@@ -57,7 +59,8 @@ int fill_geom(const mdconv_desc *d, Geom *g) {
     set_error("ndim must be 2 or 3 (got %d)", d->ndim);
     return MDCONV_EINVAL;
   }
-  if (d->dtype != MDCONV_F32 && d->dtype != MDCONV_F16 && d->dtype != MDCONV_F64) {
+  if (d->dtype != MDCONV_F32 && d->dtype != MDCONV_F16 && d->dtype != MDCONV_F64 &&
+      d->dtype != MDCONV_BF16) {
     set_error("unsupported dtype %d", d->dtype);
     return MDCONV_EINVAL;
   }
@@ -173,6 +176,13 @@ static int run_forward(const mdconv_desc *d, int nd, int modulated, Tensors t, v
   if (g.with_bias && (rc = require(t.bias, "bias"))) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int path = current_path();
+  // 16-bit tensors: native fp16 / bf16 kernels (hp_*.hip) when the shape qualifies
+  if (path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, false)) {
+    if ((rc = check_ws(ws, ws_bytes, hp_workspace_bytes(g, d->dtype, false)))) return rc;
+    g_last_path = MDCONV_PATH_MFMA;
+    g_last_kernels = MDCONV_KERNELS_HP;
+    return hp_forward(g, d->dtype, t, ws, s);
+  }
   const bool mfma_ok = mfma_supported(g, d->dtype, false);
   if (path == MDCONV_PATH_MFMA && !mfma_ok) {
     set_error("MDCONV_PATH=mfma but this shape/dtype is not supported by the MFMA kernels");
@@ -181,9 +191,11 @@ static int run_forward(const mdconv_desc *d, int nd, int modulated, Tensors t, v
   if (mfma_ok && path != MDCONV_PATH_DIRECT) {
     if ((rc = check_ws(ws, ws_bytes, mfma_workspace_bytes(g, d->dtype, false)))) return rc;
     g_last_path = MDCONV_PATH_MFMA;
+    g_last_kernels = MDCONV_KERNELS_F32;
     return mfma_forward(g, d->dtype, t, ws, s);
   }
   g_last_path = MDCONV_PATH_DIRECT;
+  g_last_kernels = MDCONV_KERNELS_DIRECT;
   return direct_forward(g, d->dtype, t, s);
 }
 
@@ -209,6 +221,12 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
   hipStream_t s = (hipStream_t)stream;
   g.acc_data = g.acc_w = g_accumulate;
   const int path = current_path();
+  if (path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, true)) {
+    if ((rc = check_ws(ws, ws_bytes, hp_workspace_bytes(g, d->dtype, true)))) return rc;
+    g_last_path = MDCONV_PATH_MFMA;
+    g_last_kernels = MDCONV_KERNELS_HP;
+    return hp_backward(g, d->dtype, t, ws, s);
+  }
   const bool mfma_ok = mfma_supported(g, d->dtype, true);
   if (path == MDCONV_PATH_MFMA && !mfma_ok) {
     set_error("MDCONV_PATH=mfma but this shape/dtype is not supported by the MFMA kernels");
@@ -217,12 +235,14 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
   if (mfma_ok && path != MDCONV_PATH_DIRECT) {
     if ((rc = check_ws(ws, ws_bytes, mfma_workspace_bytes(g, d->dtype, true)))) return rc;
     g_last_path = MDCONV_PATH_MFMA;
+    g_last_kernels = MDCONV_KERNELS_F32;
     return mfma_backward(g, d->dtype, t, ws, s);
   }
   g_last_path = MDCONV_PATH_DIRECT;
+  g_last_kernels = MDCONV_KERNELS_DIRECT;
   if (!g_accumulate) {
     // the direct kernels scatter with atomics, so "overwrite" means: clear first
-    const size_t es = d->dtype == MDCONV_F64 ? 8 : (d->dtype == MDCONV_F16 ? 2 : 4);
+    const size_t es = d->dtype == MDCONV_F64 ? 8 : (d->dtype == MDCONV_F32 ? 4 : 2);
     const size_t n_off = (size_t)g.B * g.DG * g.nd * g.K * g.S_o, n_m = (size_t)g.B * g.DG * g.K * g.S_o;
     if ((rc = zero_bytes(t.grad_input, (size_t)g.B * g.C * g.S_i * es, s)) ||
         (rc = zero_bytes(t.grad_offset, n_off * es, s)) ||
@@ -278,6 +298,7 @@ size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward) {
   Geom g;
   if (fill_geom(d, &g)) return 0;
   if (current_path() == MDCONV_PATH_DIRECT) return 0;
+  if (hp_supported(g, d->dtype, backward != 0)) return hp_workspace_bytes(g, d->dtype, backward != 0);
   if (!mfma_supported(g, d->dtype, backward != 0)) return 0;
   return mfma_workspace_bytes(g, d->dtype, backward != 0);
 }
@@ -306,6 +327,7 @@ int mdconv_set_path(int path) {
   return prev;
 }
 int mdconv_last_path(void) { return g_last_path; }
+int mdconv_last_kernels(void) { return g_last_kernels; }
 
 int mdconv_deform_conv2d_forward(const mdconv_desc *d, const void *input, const void *weight,
                                  const void *bias, const void *offset, void *output,

@@ -75,6 +75,7 @@ template <int ND, typename A> struct TapCoef {
   int delta[ND]; // index step low -> high per axis (0 when clamped)
   int last_lc;   // clamped low coordinate on the last (contiguous) axis
   bool inside;   // -1 < p_a < size_a on every axis
+  bool vl[ND], vh[ND];   // the low / high side lies inside the image (the reference reads it)
 };
 
 // Decompose a flattened output pixel index into per-axis coordinates.
@@ -126,6 +127,8 @@ __device__ __forceinline__ void make_tap(const Geom &g, const int *o, const int 
     const bool big = d > (A)MDCONV_EPS;
     const bool vh_load = vh && (!bwd || !g.load_eps || big);
     const bool vh_atom = vh && (!g.atom_eps || big);
+    tc.vl[a] = vl;
+    tc.vh[a] = vh_load;
     tc.wl[a] = vl ? (A)1 - d : (A)0;
     tc.wh[a] = vh_load ? d : (A)0;
     tc.wha[a] = vh_atom ? d : (A)0;

@@ -22,7 +22,7 @@ def capi():
 def test_library_exports_every_declared_symbol(capi):
     hdr = open(os.path.join(ROOT, "include", "mdconv.h")).read()
     declared = set(re.findall(r"\b(mdconv_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) == 19 and declared == set(capi.EXPORTS)
+    assert len(declared) == len(capi.EXPORTS) >= 20 and declared == set(capi.EXPORTS)
     L = capi.lib()
     for name in declared:
         assert getattr(L, name) is not None

@@ -73,7 +73,29 @@ def rel_err(a, b):
     return ((a - b).abs().max() / max(1.0, b.abs().max().item())).item()
 
 
-def assert_close(name, got, want, tol):
+def elem_err(a, b):
+    """Per-element criterion: max over elements of |a-b| / (rms(b) + |b|).  Unlike rel_err it does
+    not let small elements of a large-magnitude tensor (grad_weight at cfg2: |max| ~ 3e2) hide
+    behind the tensor's maximum: the absolute slack is tol * rms(b), not tol * max|b|."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if b.numel() == 0:
+        return 0.0
+    rms = b.pow(2).mean().sqrt().item()
+    return ((a - b).abs() / (max(rms, 1e-30) + b.abs())).max().item()
+
+
+WORST = {}   # name -> worst (scaled max error, per-element error) seen in this process
+
+
+def assert_close(name, got, want, tol, elem_tol=None):
+    """Both criteria must hold: scaled max error <= tol and per-element error <= elem_tol
+    (default: the same tol)."""
     assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert torch.isfinite(got.float()).all(), "%s: non-finite values" % name
     e = rel_err(got, want)
+    pe = elem_err(got, want)
+    w = WORST.get(name, (0.0, 0.0))
+    WORST[name] = (max(w[0], e), max(w[1], pe))
     assert e <= tol, "%s: scaled max error %.3e > %.1e" % (name, e, tol)
+    et = tol if elem_tol is None else elem_tol
+    assert pe <= et, "%s: per-element error %.3e > %.1e (scaled max error %.3e)" % (name, pe, et, e)
