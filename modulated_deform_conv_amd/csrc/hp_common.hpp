@@ -27,7 +27,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32;
 struct U4 { u32 x, y, z, w; };   // 8 packed 16-bit elements
 
-constexpr int kHpOob = 0x7ffffff0;   // buffer offset beyond every num_records: loads 0, stores drop
+// buffer offset beyond every num_records (chunks stay below 0x7e000000 bytes) that stays positive
+// when a lane adds its small in-row offset: loads return 0, stores are dropped
+constexpr int kHpOob = 0x7f000000;
 
 // 16-bit element types.  `Raw` = the in-memory type; everything is moved around as packed u32.
 struct F16 {
@@ -136,6 +138,7 @@ struct HpDims {
   // forward
   int MB;           // output-channel blocks (of 32) per workgroup: 1, 2, 4 or 8
   int oranges;      // workgroup rows along C_out = ceil(oblks / MB)
+  int fwd_nmax;     // most output-channel blocks any 16-channel chunk can touch inside one row
   // backward
   int nks;          // GEMM-1 k-steps (16 output channels each) per 32-channel block
   int MB2;          // GEMM-2 output-channel blocks per 32-channel block

@@ -32,7 +32,7 @@ bool hp_enabled() {
 size_t hp_chunk_limit() {
   static size_t lim = 0;
   if (!lim) {
-    lim = ((size_t)1 << 31) - (1 << 16);
+    lim = (size_t)0x7e000000;   // below kHpOob
     const char *e = getenv("MDCONV_CHUNK_LIMIT_BYTES");
     if (e && atoll(e) > 0 && (size_t)atoll(e) < lim) lim = (size_t)atoll(e);
   }
@@ -99,6 +99,16 @@ HpDims hp_dims(const Geom &g) {
   hd.oblks = hd.Op / 32;
   hd.MB = hd.oblks >= 5 ? 8 : (hd.oblks >= 3 ? 4 : hd.oblks);
   hd.oranges = (hd.oblks + hd.MB - 1) / hd.MB;
+  hd.fwd_nmax = 1;
+  for (int orange = 0; orange < hd.oranges; ++orange) {
+    const int b_lo = orange * hd.MB, b_hi = (b_lo + hd.MB < hd.oblks ? b_lo + hd.MB : hd.oblks) - 1;
+    for (int ch = 0; ch * 16 < g.C; ++ch) {
+      const int g_lo = (ch * 16) / g.Cg, g_hi = (ch * 16 + 15 < g.C ? ch * 16 + 15 : g.C - 1) / g.Cg;
+      const int ob_lo = (g_lo * g.Og) / 32 > b_lo ? (g_lo * g.Og) / 32 : b_lo;
+      const int ob_hi = ((g_hi + 1) * g.Og - 1) / 32 < b_hi ? ((g_hi + 1) * g.Og - 1) / 32 : b_hi;
+      if (ob_hi - ob_lo + 1 > hd.fwd_nmax) hd.fwd_nmax = ob_hi - ob_lo + 1;
+    }
+  }
   // backward: widest output-channel range (32-aligned) any 32-channel block needs
   int span = 32, base_max = 0;
   for (int cblk = 0; cblk < hd.cblks; ++cblk) {
@@ -168,8 +178,14 @@ int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t
     tc.output = (char *)t.output + (size_t)b0 * g.O * g.S_o * 2;
     if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
     profile_mark(0, true, stream);
-    rc = hp_forward_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
-                           (const int2 *)(base + L.off_tab), stream);
+    // quad-contiguous gathers (hp_fwd2.hip) unless a 64-channel stage would straddle deformable groups
+    static const int fwd_ver = getenv("MDCONV_HP_FWD") ? atoi(getenv("MDCONV_HP_FWD")) : 2;
+    if (fwd_ver == 2 && (g.DG == 1 || (g.Cdg % 64 == 0 && hd.oranges == 1)))
+      rc = hp_forward2_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+                              (const int2 *)(base + L.off_tab), stream);
+    else
+      rc = hp_forward_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+                             (const int2 *)(base + L.off_tab), stream);
     profile_mark(0, false, stream);
     if (rc) return rc;
   }
@@ -205,9 +221,15 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
     if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
     if ((rc = csr_zero_f32(gc, cnt, stream))) return rc;
     profile_mark(1, true, stream);
-    rc = hp_backward_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
-                            (const int4 *)(base + L.off_tab), base + L.off_gcol,
-                            (float *)(base + L.off_part), cnt, stream);
+    static const int bwd_ver = getenv("MDCONV_HP_BWD") ? atoi(getenv("MDCONV_HP_BWD")) : 2;
+    if (bwd_ver == 2 && g.DG <= 4 && hp_bwd2_lds_bytes(gc, hd) <= 160 * 1024)
+      rc = hp_backward2_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+                               (const int4 *)(base + L.off_tab), base + L.off_gcol,
+                               (float *)(base + L.off_part), cnt, stream);
+    else
+      rc = hp_backward_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+                              (const int4 *)(base + L.off_tab), base + L.off_gcol,
+                              (float *)(base + L.off_part), cnt, stream);
     profile_mark(1, false, stream);
     if (rc) return rc;
     if ((rc = hp_reduce_grad_weight(gc, hd, dtype, (const float *)(base + L.off_part),

@@ -26,10 +26,20 @@ int hp_grad_bias(const Geom &g, int dtype, const void *grad_output, void *grad_b
 int hp_forward_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
                       const void *wpf, const int2 *ctab, hipStream_t stream);
 
+// hp_fwd2.hip: the same contraction with quad-contiguous (line-wide) gathers
+int hp_forward2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
+                       const void *wpf, const int2 *ctab, hipStream_t stream);
+
 // hp_bwd.hip: GEMM-1 + coordinate gradients + grad_col + GEMM-2, one gather pass
 int hp_backward_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
                        const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                        hipStream_t stream);
+
+// hp_bwd2.hip: the same kernel with line-wide gathers (thread roles change between phases)
+size_t hp_bwd2_lds_bytes(const Geom &g, const HpDims &hd);
+int hp_backward2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
+                        const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
+                        hipStream_t stream);
 
 // hp_col2im.hip: inverse scatter map (count inside hp_bwd) + gather
 int hp_csr_build(const Geom &g, int dtype, const Tensors &t, int *cnt, int *rowptr, void *entries,

@@ -56,10 +56,15 @@ def run(name):
         f = lambda: M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo)
         bw = lambda: M.modulated_deform_conv2d_backward_cuda(x, w, b, off, m, go, *geo)
         ns = B * C * K * math.prod(sp)
-    elif name == "cfg5":   # MDCN3d C=128 16x64x64 B=8/GPU dil 2 fp16
+    elif name in ("cfg5", "cfg5z", "cfg5l2"):   # MDCN3d C=128 16x64x64 B=8/GPU dil 2 fp16
+        # cfg5z: zero offsets (coherent gathers); cfg5l2: 8x32x32 images, B=64 (input of a few images fits L2)
         B, C, O, K, sp = 8, 128, 128, 27, (16, 64, 64)
+        if name == "cfg5l2":
+            B, sp = 64, (8, 32, 32)
         h = lambda t: t.cuda().half().contiguous()
         x, off, m = h(rn(B, C, *sp)), h(rn(B, 3 * K, *sp)), h(torch.sigmoid(rn(B, K, *sp)))
+        if name == "cfg5z":
+            off.zero_()
         w = h((torch.rand(O, C, 3, 3, 3, generator=g) * 2 - 1) / math.sqrt(C * K))
         b, go = x.new_empty(0), h(rn(B, O, *sp))
         geo = (3, 3, 3, 1, 1, 1, 2, 2, 2, 2, 2, 2, 1, 1, 64, False)
