@@ -110,11 +110,16 @@ void mdconv_profile_reset(void);
 int mdconv_set_accumulate(int on);
 
 /* Multi-GPU overlap: every backward records an event on its stream as soon
- * as grad_weight and grad_bias are final -- before the grad_input gather is enqueued.  This makes
- * `stream` (a hipStream_t, e.g. the communication stream) wait for that point of the LAST backward
- * issued by the calling thread, so the all-reduce of grad_weight || grad_bias runs under the rest
- * of the backward.  Returns MDCONV_EINVAL if this thread has not run a backward yet. */
+ * as grad_weight and grad_bias are final -- before the grad_input gather is enqueued.
+ * mdconv_stream_wait_weight_ready_on() makes `stream` (a hipStream_t, e.g. the communication
+ * stream) wait for that point of the LAST backward issued on `producer_stream` of the current
+ * device, whichever host thread issued it (PyTorch runs autograd backwards on worker threads), so
+ * the all-reduce of grad_weight || grad_bias runs under the rest of the backward.
+ * mdconv_stream_wait_weight_ready() is the stream-less form: the most recent backward on the
+ * current device (use the keyed form when several streams run backwards concurrently).
+ * Both return MDCONV_EINVAL if no such backward has been issued. */
 int mdconv_stream_wait_weight_ready(void *stream);
+int mdconv_stream_wait_weight_ready_on(void *stream, void *producer_stream);
 
 /* --- replaces deform_conv2d_forward_cuda (deformable_conv.cu:117-123) ---------------------- */
 int mdconv_deform_conv2d_forward(const mdconv_desc *d, const void *input, const void *weight,

@@ -16,7 +16,7 @@ EXPORTS = (
     "mdconv_abi_version", "mdconv_last_error", "mdconv_out_size", "mdconv_workspace_bytes",
     "mdconv_set_path", "mdconv_last_path", "mdconv_last_kernels",
     "mdconv_profile_enable", "mdconv_profile_read", "mdconv_profile_reset",
-    "mdconv_stream_wait_weight_ready", "mdconv_set_accumulate",
+    "mdconv_stream_wait_weight_ready", "mdconv_stream_wait_weight_ready_on", "mdconv_set_accumulate",
     "mdconv_deform_conv2d_forward", "mdconv_deform_conv2d_backward",
     "mdconv_modulated_deform_conv2d_forward", "mdconv_modulated_deform_conv2d_backward",
     "mdconv_deform_conv3d_forward", "mdconv_deform_conv3d_backward",
@@ -60,6 +60,8 @@ def lib():
         L.mdconv_set_accumulate.argtypes = [ctypes.c_int]
         L.mdconv_stream_wait_weight_ready.restype = ctypes.c_int
         L.mdconv_stream_wait_weight_ready.argtypes = [ctypes.c_void_p]
+        L.mdconv_stream_wait_weight_ready_on.restype = ctypes.c_int
+        L.mdconv_stream_wait_weight_ready_on.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.mdconv_last_kernels.restype = ctypes.c_int
         for name in EXPORTS[10:]:
             getattr(L, name).restype = ctypes.c_int
@@ -104,10 +106,16 @@ class overwrite_grads:
         return False
 
 
-def stream_wait_weight_ready(stream):
+def stream_wait_weight_ready(stream, producer=None):
     """Make `stream` (a torch.cuda.Stream) wait until grad_weight / grad_bias of the last backward
-    issued by this thread are final (the grad_input gather may still be running)."""
-    rc = lib().mdconv_stream_wait_weight_ready(ctypes.c_void_p(stream.cuda_stream))
+    issued on `producer` (a torch.cuda.Stream; default: the most recent backward on the current
+    device) are final -- the grad_input gather may still be running.  Works whichever host thread
+    issued that backward (autograd worker threads included)."""
+    if producer is None:
+        rc = lib().mdconv_stream_wait_weight_ready(ctypes.c_void_p(stream.cuda_stream))
+    else:
+        rc = lib().mdconv_stream_wait_weight_ready_on(ctypes.c_void_p(stream.cuda_stream),
+                                                      ctypes.c_void_p(producer.cuda_stream))
     if rc != 0:
         raise RuntimeError(last_error())
 

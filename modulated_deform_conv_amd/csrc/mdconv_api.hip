@@ -7,6 +7,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "mdconv_common.hpp"
 #include "hp_kernels.hpp"
 #include "mfma_kernels.hpp"
@@ -17,11 +22,13 @@ static thread_local char g_err[512] = "";
 static thread_local int g_last_path = 0;
 static thread_local int g_last_kernels = 0;
 static thread_local int g_accumulate = 1;
-// "grad_weight / grad_bias are final" event of the last backward of this thread
-static thread_local hipEvent_t g_wready = nullptr;
-static thread_local int g_wready_dev = -1;
-static thread_local bool g_wready_set = false;
-static int g_path = -1;  // -1 = not initialised from the environment yet
+// "grad_weight / grad_bias are final" events: one per (device, producer stream), shared by all
+// host threads (autograd runs the backward on its own worker thread), plus the most recent one per
+// device for the stream-less legacy query
+static std::mutex g_wready_mu;
+static std::map<std::pair<int, hipStream_t>, hipEvent_t> g_wready;
+static std::map<int, hipEvent_t> g_wready_latest;
+static std::atomic<int> g_path{-1};  // -1 = not initialised from the environment yet
 
 void set_error(const char *fmt, ...) {
   va_list ap;
@@ -40,14 +47,17 @@ int check_launch(const char *what) {
 }
 
 static int current_path() {
-  if (g_path < 0) {
+  int p = g_path.load(std::memory_order_relaxed);
+  if (p < 0) {
     const char *e = getenv("MDCONV_PATH");
-    int p = MDCONV_PATH_AUTO;
+    p = MDCONV_PATH_AUTO;
     if (e && !strcmp(e, "direct")) p = MDCONV_PATH_DIRECT;
     if (e && !strcmp(e, "mfma")) p = MDCONV_PATH_MFMA;
-    g_path = p;
+    int expect = -1;
+    g_path.compare_exchange_strong(expect, p);
+    p = g_path.load();
   }
-  return g_path;
+  return p;
 }
 
 int fill_geom(const mdconv_desc *d, Geom *g) {
@@ -258,23 +268,44 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
 int record_weight_ready(hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return MDCONV_ELAUNCH;
-  if (g_wready && dev != g_wready_dev) {
-    (void)hipEventDestroy(g_wready);
-    g_wready = nullptr;
+  std::lock_guard<std::mutex> lock(g_wready_mu);
+  hipEvent_t &ev = g_wready[std::make_pair(dev, stream)];
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    ev = nullptr;
+    set_error("hipEventCreate failed");
+    return MDCONV_ELAUNCH;
   }
-  if (!g_wready) {
-    if (hipEventCreateWithFlags(&g_wready, hipEventDisableTiming) != hipSuccess) {
-      g_wready = nullptr;
-      set_error("hipEventCreate failed");
-      return MDCONV_ELAUNCH;
-    }
-    g_wready_dev = dev;
-  }
-  if (hipEventRecord(g_wready, stream) != hipSuccess) {
+  if (hipEventRecord(ev, stream) != hipSuccess) {
     set_error("hipEventRecord failed");
     return MDCONV_ELAUNCH;
   }
-  g_wready_set = true;
+  g_wready_latest[dev] = ev;
+  return MDCONV_OK;
+}
+
+static int wait_weight_ready(hipStream_t waiter, bool keyed, hipStream_t producer) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MDCONV_ELAUNCH;
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_wready_mu);
+    if (keyed) {
+      auto it = g_wready.find(std::make_pair(dev, producer));
+      if (it != g_wready.end()) ev = it->second;
+    } else {
+      auto it = g_wready_latest.find(dev);
+      if (it != g_wready_latest.end()) ev = it->second;
+    }
+  }
+  if (!ev) {
+    set_error(keyed ? "no backward has been issued on that stream of this device"
+                    : "no backward has been issued on this device");
+    return MDCONV_EINVAL;
+  }
+  if (hipStreamWaitEvent(waiter, ev, 0) != hipSuccess) {
+    set_error("hipStreamWaitEvent failed");
+    return MDCONV_ELAUNCH;
+  }
   return MDCONV_OK;
 }
 
@@ -310,20 +341,16 @@ int mdconv_set_accumulate(int on) {
 }
 
 int mdconv_stream_wait_weight_ready(void *stream) {
-  if (!g_wready_set) {
-    set_error("no backward has been issued by this thread");
-    return MDCONV_EINVAL;
-  }
-  if (hipStreamWaitEvent((hipStream_t)stream, g_wready, 0) != hipSuccess) {
-    set_error("hipStreamWaitEvent failed");
-    return MDCONV_ELAUNCH;
-  }
-  return MDCONV_OK;
+  return wait_weight_ready((hipStream_t)stream, false, nullptr);
+}
+
+int mdconv_stream_wait_weight_ready_on(void *stream, void *producer_stream) {
+  return wait_weight_ready((hipStream_t)stream, true, (hipStream_t)producer_stream);
 }
 
 int mdconv_set_path(int path) {
   const int prev = current_path();
-  if (path >= MDCONV_PATH_AUTO && path <= MDCONV_PATH_MFMA) g_path = path;
+  if (path >= MDCONV_PATH_AUTO && path <= MDCONV_PATH_MFMA) g_path.store(path);
   return prev;
 }
 int mdconv_last_path(void) { return g_last_path; }

@@ -4,13 +4,17 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 namespace mdconv {
 
 namespace {
 
-bool g_prof_on = false;
+// benchmark hooks: process-wide, guarded so that a threaded host cannot corrupt the event lists
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
 struct ProfPair { hipEvent_t a, b; };
 std::vector<ProfPair> g_prof[3];
 size_t g_prof_used[3] = {0, 0, 0};
@@ -66,7 +70,8 @@ int zero_bytes(void *p, size_t bytes, hipStream_t s) {
 }
 
 void profile_mark(int which, bool begin, hipStream_t stream) {
-  if (!g_prof_on || which < 0 || which > 2) return;
+  if (!g_prof_on.load(std::memory_order_relaxed) || which < 0 || which > 2) return;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   if (begin) {
     if (g_prof_used[which] == g_prof[which].size()) {
       ProfPair p;
@@ -186,7 +191,19 @@ bool make_plan(const Geom &g, int dtype, bool backward, Plan *p) {
   const size_t per_in = (size_t)g.C * g.S_i * 4, per_out = (size_t)g.O * g.S_o * 4;
   const size_t per_col = (size_t)g.C * g.K * g.S_o * 4;
   size_t per = per_in > per_out ? per_in : per_out;
-  if (backward && per_col > per) per = per_col;
+  if (backward) {
+    // every workspace buffer the backward kernels address with 32-bit buffer offsets must stay
+    // below the limit for one chunk: grad_col, the packed grad_out (rows padded to the GEMM-2 tile:
+    // up to 256 output channels even for small C_out), the tap table and the scatter lists
+    const BwdDims b1 = bwd_dims(chunk_geom(g, 1));
+    const size_t per_ga = (size_t)g.S_o * b1.OgpB * 4;
+    const size_t per_tab = (size_t)g.DG * g.K * g.S_o * 2 * (1 << g.nd) * 4;
+    const size_t per_ent = (size_t)g.DG * g.K * g.S_o * (1 << (g.nd - 1)) * 16;
+    if (per_col > per) per = per_col;
+    if (per_ga > per) per = per_ga;
+    if (per_tab > per) per = per_tab;
+    if (per_ent > per) per = per_ent;
+  }
   const size_t kLim = chunk_limit();
   if (per >= kLim) return false;
   int bc = (int)(kLim / per);
@@ -430,17 +447,18 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
 
 extern "C" {
 int mdconv_profile_enable(int on) {
-  const int prev = mdconv::g_prof_on ? 1 : 0;
-  mdconv::g_prof_on = on != 0;
+  const int prev = mdconv::g_prof_on.exchange(on != 0) ? 1 : 0;
   return prev;
 }
 void mdconv_profile_reset(void) {
+  std::lock_guard<std::mutex> lock(mdconv::g_prof_mu);
   for (int i = 0; i < 3; ++i) mdconv::g_prof_used[i] = 0;
 }
 int mdconv_profile_read(int which, double *total_ms) {
   if (which < 0 || which > 2) return 0;
   double tot = 0;
   int n = 0;
+  std::lock_guard<std::mutex> lock(mdconv::g_prof_mu);
   for (size_t i = 0; i < mdconv::g_prof_used[which]; ++i) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, mdconv::g_prof[which][i].a, mdconv::g_prof[which][i].b) == hipSuccess) {

@@ -80,15 +80,18 @@ class FusedGradAllReduce:
         in between (include/mdconv.h: mdconv_stream_wait_weight_ready).  The collective is issued
         on a communication stream that waits for that event only, so it runs while the gather is
         still executing; the caller's stream re-joins afterwards ("issue it
-        on a side stream as soon as GEMM-2/bias finish").  Call it right after the backward entry
-        point returned, from the same thread.  CPU tensors (gloo tests) take the plain path."""
+        on a side stream as soon as GEMM-2/bias finish").  Call it after the backward that produced
+        the gradients has been issued on the CURRENT stream -- directly through MDCONV_CUDA or via
+        ``loss.backward()`` (autograd runs the op on a worker thread but on the forward's stream;
+        the event is keyed by (device, stream), not by thread).  CPU tensors (gloo tests) take the
+        plain path."""
         if not grad_weight.is_cuda:
             return self(grad_weight, grad_bias)
         from . import _capi
         if self._comm is None:
             self._comm = torch.cuda.Stream()
         main = torch.cuda.current_stream()
-        _capi.stream_wait_weight_ready(self._comm)
+        _capi.stream_wait_weight_ready(self._comm, producer=main)
         with torch.cuda.stream(self._comm):
             self(grad_weight, grad_bias)
         for g in (grad_weight, grad_bias):

@@ -174,9 +174,10 @@ def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
         _capi.set_path(prev)
     got = {"grad_input": gi, "grad_weight": gw, "grad_offset": goff, "grad_mask": gm,
            "grad_bias": gb if case["bias"] else None}
-    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    # fp16: the two runs round differently ordered sums to 11 bits (atomics / CSR list order)
+    tol, elem_tol = (1e-5, None) if dtype == torch.float32 else (2e-3, 1e-2)
     for key, g in got.items():
         if g is None or want[key] is None:
             continue
         assert torch.isfinite(g).all(), key
-        assert_close(key, g, want[key], tol)
+        assert_close(key, g, want[key], tol, elem_tol)

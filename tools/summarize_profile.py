@@ -77,6 +77,11 @@ def main(src, tag):
         wr = v.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
         summary[k] = {"fetch_bytes_raw": f_raw, "fetch_bytes_x2_gfx950": 2 * f_raw, "write_bytes": wr,
                       "hbm_bytes_per_launch": 2 * f_raw + wr}
+    # stamp: hash of the kernel sources the counters were collected on (bench.py refuses the traffic
+    # figure when the sources it times differ); collect_profiles.sh records it on the GPU box
+    stamp_file = os.path.join(src, "kernel_sources_sha16.txt")
+    if os.path.exists(stamp_file):
+        summary["_kernel_sources_sha16"] = open(stamp_file).read().strip()
     json.dump(summary, open(os.path.join(out_dir, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     bench_json = None
     bj = os.path.join(src, "bench_full.json")
