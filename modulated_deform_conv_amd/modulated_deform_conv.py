@@ -68,6 +68,15 @@ def _make_function(nd, modulated, name):
     def _forward(ctx, input, offset, mask, weight, bias):
         needs_grad = weight.requires_grad or offset.requires_grad or input.requires_grad or \
             (modulated and mask.requires_grad)
+        # gradients go back in the dtypes the caller's tensors have (the autocast cast below happens
+        # inside this Function, so autograd does not see it)
+        ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (input, offset, mask, weight, bias))
+        if torch.is_autocast_enabled("cuda"):
+            # AMP: run in the autocast dtype on the native 16-bit kernels
+            # (fp16 / bf16 operands, fp32 coordinates, interpolation weights and accumulators)
+            dt = torch.get_autocast_dtype("cuda")
+            cast = lambda t: t if t is None or not t.is_floating_point() or t.dtype == dt else t.to(dt)
+            input, offset, mask, weight, bias = (cast(t) for t in (input, offset, mask, weight, bias))
         if needs_grad:
             saved = (input, offset, mask, weight, bias) if modulated else (input, offset, weight, bias)
             ctx.save_for_backward(*saved)
@@ -110,6 +119,9 @@ def _make_function(nd, modulated, name):
                         grad_output, *geo)
         if not ctx.with_bias:
             grad_bias = None
+        back = lambda g, dt: g if g is None or dt is None or g.dtype == dt else g.to(dt)
+        grad_input, grad_offset, grad_mask, grad_weight, grad_bias = (
+            back(g, dt) for g, dt in zip((grad_input, grad_offset, grad_mask, grad_weight, grad_bias), ctx.in_dtypes))
         head = (grad_input, grad_offset, grad_mask) if modulated else (grad_input, grad_offset)
         return head + (grad_weight, grad_bias) + (None,) * 6
 
@@ -128,9 +140,9 @@ def _make_function(nd, modulated, name):
         return _output_shape(input, weight, ctx.stride, ctx.padding, ctx.dilation)
 
     return type(name, (Function,), {
-        # AMP: under torch.autocast the op runs in fp32 -- coordinates and
-        # accumulation need it -- and autocast is disabled inside backward.
-        "forward": staticmethod(custom_fwd(forward, device_type="cuda", cast_inputs=torch.float32)),
+        # AMP: custom_fwd records the autocast state (custom_bwd replays it in backward); the cast to
+        # the autocast dtype happens in _forward so that fp16 AND bf16 autocast both work
+        "forward": staticmethod(custom_fwd(forward, device_type="cuda")),
         "backward": staticmethod(custom_bwd(once_differentiable(_backward), device_type="cuda")),
         "_infer_shape": staticmethod(_infer_shape),
         "__doc__": "%s-D %sdeformable convolution (reference modulated_deform_conv.py)." % (
@@ -251,18 +263,36 @@ def _make_pack(base, name):
         base.__init__(self, *args, **kwargs)
         self._make_side_convs()
 
+    def _plain(m, conv_cls):
+        """True if calling F.conv directly on m's parameters is equivalent to calling m: an
+        unmodified nn.ConvNd without hooks (weight_norm / spectral_norm / pruning recompute
+        `.weight` in a pre-forward hook; quantisation or LoRA wrappers replace the module)."""
+        return (type(m) is conv_cls and not m._forward_hooks and not m._forward_pre_hooks
+                and not m._backward_hooks and not getattr(m, "_backward_pre_hooks", None)
+                and m.padding_mode == "zeros" and m.groups == 1 and m.bias is not None
+                and not torch.nn.modules.module._global_forward_hooks
+                and not torch.nn.modules.module._global_forward_pre_hooks)
+
     if base._modulated:
         def forward(self, x):
             # ONE side convolution for offset and mask (SURVEY.md section 8f-1): the two parameter
             # sets stay separate modules (state_dict keys conv_offset.* / conv_mask.* as in the
             # reference) and are concatenated along the output channels, so the input is read once
-            # and one library launch replaces two.  Same numbers as two convolutions.
+            # and one library launch replaces two.  Same numbers as two convolutions.  Only when
+            # both are plain convolutions of identical geometry; otherwise the modules are CALLED,
+            # exactly like the reference (:779-783), so hooks / parametrisations / replaced
+            # submodules keep working.
             co, cm = self.conv_offset, self.conv_mask
-            conv = torch.nn.functional.conv2d if self._nd == 2 else torch.nn.functional.conv3d
-            y = conv(x, torch.cat((co.weight, cm.weight)), torch.cat((co.bias, cm.bias)),
-                     co.stride, co.padding, co.dilation)
-            n_off = co.out_channels
-            return base.forward(self, x, y[:, :n_off].contiguous(), y[:, n_off:].contiguous())
+            conv_cls = nn.Conv2d if self._nd == 2 else nn.Conv3d
+            if (_plain(co, conv_cls) and _plain(cm, conv_cls) and co.stride == cm.stride
+                    and co.padding == cm.padding and co.dilation == cm.dilation
+                    and co.kernel_size == cm.kernel_size and co.weight.dtype == cm.weight.dtype):
+                conv = torch.nn.functional.conv2d if self._nd == 2 else torch.nn.functional.conv3d
+                y = conv(x, torch.cat((co.weight, cm.weight)), torch.cat((co.bias, cm.bias)),
+                         co.stride, co.padding, co.dilation)
+                n_off = co.out_channels
+                return base.forward(self, x, y[:, :n_off].contiguous(), y[:, n_off:].contiguous())
+            return base.forward(self, x, co(x), cm(x))
     else:
         def forward(self, x):
             return base.forward(self, x, self.conv_offset(x))

@@ -113,21 +113,72 @@ def test_pack_fused_side_conv_equals_two_convs(nd):
         assert_close("grad", a, b, 1e-4)
 
 
-def test_autocast_runs_in_fp32():
-    """AMP integration: under autocast the op computes in fp32 and returns fp32."""
-    from modulated_deform_conv_amd import modulated_deform_conv as mdc
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_autocast_runs_on_the_native_16bit_kernels(dt):
+    """AMP integration: under autocast the op casts its inputs to the autocast dtype and runs the
+    native fp16 / bf16 kernels (fp32 coordinates and accumulation inside); fp32 leaf tensors get
+    fp32 gradients."""
+    from modulated_deform_conv_amd import modulated_deform_conv as mdc, _capi
     torch.manual_seed(0)
-    m = mdc.ModulatedDeformConv2d(16, 16, 3, padding=1, bias=True).cuda()
-    x = torch.randn(2, 16, 9, 9, device="cuda", requires_grad=True)
+    m = mdc.ModulatedDeformConv2d(32, 32, 3, padding=1, bias=True).cuda()
+    x = torch.randn(2, 32, 9, 9, device="cuda", requires_grad=True)
     off = torch.randn(2, 18, 9, 9, device="cuda")
     mask = torch.rand(2, 9, 9, 9, device="cuda")
     ref = m(x, off, mask)
-    with torch.autocast("cuda", dtype=torch.float16):
-        y = m(x.half(), off.half(), mask)        # mixed input dtypes are fine under autocast
-    assert y.dtype == torch.float32
-    assert_close("autocast", y, m(x.half().float(), off.half().float(), mask), 1e-5)
-    y.sum().backward()
-    assert x.grad is not None and torch.isfinite(x.grad).all() and ref.shape == y.shape
+    with torch.autocast("cuda", dtype=dt):
+        y = m(x, off.half(), mask)        # mixed input dtypes are fine under autocast
+    assert y.dtype == dt and _capi.last_kernels() == "hp"
+    assert_close("autocast", y.float(), ref, 2e-2 if dt == torch.float16 else 6e-2)
+    y.float().sum().backward()
+    assert x.grad is not None and x.grad.dtype == torch.float32 and torch.isfinite(x.grad).all()
+    assert m.weight.grad.dtype == torch.float32
+
+
+def test_pack_calls_hooked_side_convs_like_the_reference():
+    """A hook / parametrisation on conv_offset or conv_mask must take effect (the reference CALLS
+    the modules, modulated_deform_conv.py:779-783): the fused single-convolution path is only used
+    for plain convolutions."""
+    from modulated_deform_conv_amd import modulated_deform_conv as mdc
+    torch.manual_seed(2)
+    m = mdc.ModulatedDeformConv2dPack(8, 8, 3, padding=1, bias=True).cuda()
+    x = torch.randn(2, 8, 9, 9, device="cuda")
+    y_plain = m(x)
+    calls = []
+    h = m.conv_mask.register_forward_hook(lambda mod, inp, out: (calls.append(1), out * 0)[1])
+    y_hooked = m(x)
+    h.remove()
+    assert calls and not torch.allclose(y_plain, y_hooked)
+    assert_close("hook removed", m(x), y_plain, 1e-6)
+    torch.nn.utils.parametrizations.weight_norm(m.conv_offset)
+    y_wn = m(x)     # parametrised module: the path that calls the modules
+    y_ref = mdc.ModulatedDeformConv2d.forward(m, x, m.conv_offset(x), m.conv_mask(x))
+    assert_close("weight_norm", y_wn, y_ref, 1e-6)
+
+
+def test_overlapped_reduce_after_autograd_backward():
+    """The weights-ready event is keyed by (device, stream), not by host thread: it is found after
+    loss.backward(), which runs the op on an autograd worker thread (world size 1: the reducer
+    takes its CPU / single-process path only for the collective itself)."""
+    from modulated_deform_conv_amd import modulated_deform_conv as mdc, _capi
+    torch.manual_seed(3)
+    m = mdc.ModulatedDeformConv2d(64, 64, 3, padding=1, bias=True).cuda()
+    x = torch.randn(4, 64, 28, 28, device="cuda", requires_grad=True)
+    off = torch.randn(4, 18, 28, 28, device="cuda")
+    mask = torch.rand(4, 9, 28, 28, device="cuda")
+    m(x, off, mask).square().sum().backward()
+    ref_w, ref_b = m.weight.grad.clone(), m.bias.grad.clone()
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        m.zero_grad()
+        m(x, off, mask).square().sum().backward()
+        _capi.stream_wait_weight_ready(side, producer=torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gw, gb = m.weight.grad.clone(), m.bias.grad.clone()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(gw, ref_w) and torch.equal(gb, ref_b)
+    with pytest.raises(RuntimeError, match="no backward"):
+        _capi.stream_wait_weight_ready(side, producer=torch.cuda.Stream())
 
 
 def test_weight_ready_event_orders_a_side_stream():
