@@ -109,6 +109,15 @@ void mdconv_profile_reset(void);
  * Returns the previous mode. */
 int mdconv_set_accumulate(int on);
 
+/* Memory format of `input` for the calling thread's next calls:
+ * MDCONV_LAYOUT_NCHW (default, the reference's [B, C, spatial...]) or MDCONV_LAYOUT_CHANNELS_LAST
+ * ([B, spatial..., C], torch.channels_last / channels_last_3d).  Channels-last input is what the
+ * native 16-bit kernels gather from, so it saves their layout pass; it is accepted for fp16 / bf16
+ * tensors with C_in a multiple of 32 only (MDCONV_EUNSUPPORTED otherwise).  Every other tensor,
+ * grad_input included, keeps the reference layout.  Returns the previous setting. */
+enum { MDCONV_LAYOUT_NCHW = 0, MDCONV_LAYOUT_CHANNELS_LAST = 1 };
+int mdconv_set_input_layout(int layout);
+
 /* Multi-GPU overlap: every backward records an event on its stream as soon
  * as grad_weight and grad_bias are final -- before the grad_input gather is enqueued.
  * mdconv_stream_wait_weight_ready_on() makes `stream` (a hipStream_t, e.g. the communication

@@ -22,9 +22,20 @@ _DTYPES = {torch.float32: _capi.F32, torch.float16: _capi.F16, torch.float64: _c
            torch.bfloat16: _capi.BF16}
 
 
+def _is_channels_last(t):
+    """`t` is a dense channels-last tensor the native 16-bit kernels can gather from directly
+    (torch.channels_last / channels_last_3d, fp16 / bf16, C a multiple of 32)."""
+    if t.dim() not in (4, 5) or t.dtype not in (torch.float16, torch.bfloat16) or t.shape[1] % 32:
+        return False
+    fmt = torch.channels_last if t.dim() == 4 else torch.channels_last_3d
+    return t.is_contiguous(memory_format=fmt)
+
+
 def _check_contig(**tensors):
     for name, t in tensors.items():
-        if not t.is_contiguous():
+        # extension of the reference's check (mdeformable_conv.cu:127-131): a channels-last `input`
+        # is accepted where the kernels consume that layout anyway (SURVEY.md section 8f-3)
+        if not t.is_contiguous() and not (name == "input" and _is_channels_last(t)):
             raise RuntimeError("%s tensor has to be contiguous" % name)
 
 
@@ -91,7 +102,8 @@ def _same(ref, **tensors):
 
 def _run(fn_name, d, backward, args_before_ws, input):
     L = _capi.lib()
-    with torch.cuda.device(input.device):
+    cl = not input.is_contiguous() and _is_channels_last(input)
+    with torch.cuda.device(input.device), _capi.channels_last_input(cl):
         ws_bytes = L.mdconv_workspace_bytes(ctypes.byref(d), int(backward))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device) if ws_bytes else None
         stream = torch.cuda.current_stream().cuda_stream
@@ -203,7 +215,7 @@ def modulated_deform_conv2d_backward_cuda(input, weight, bias, offset, mask, gra
     # the reference allocates zeros here (mdeformable_conv.cu:404-411) and adds into them; this
     # entry point owns its results, so it allocates uninitialised memory and asks the library to
     # WRITE the gradients (no zero fills, no read-modify-write)
-    grad_input = torch.empty_like(input)
+    grad_input = torch.empty_like(input, memory_format=torch.contiguous_format)
     grad_offset = torch.empty_like(offset)
     grad_mask = torch.empty_like(mask)
     grad_weight = torch.empty_like(weight)

@@ -16,7 +16,7 @@ EXPORTS = (
     "mdconv_abi_version", "mdconv_last_error", "mdconv_out_size", "mdconv_workspace_bytes",
     "mdconv_set_path", "mdconv_last_path", "mdconv_last_kernels",
     "mdconv_profile_enable", "mdconv_profile_read", "mdconv_profile_reset",
-    "mdconv_stream_wait_weight_ready", "mdconv_stream_wait_weight_ready_on", "mdconv_set_accumulate",
+    "mdconv_stream_wait_weight_ready", "mdconv_stream_wait_weight_ready_on", "mdconv_set_accumulate", "mdconv_set_input_layout",
     "mdconv_deform_conv2d_forward", "mdconv_deform_conv2d_backward",
     "mdconv_modulated_deform_conv2d_forward", "mdconv_modulated_deform_conv2d_backward",
     "mdconv_deform_conv3d_forward", "mdconv_deform_conv3d_backward",
@@ -58,6 +58,8 @@ def lib():
         L.mdconv_profile_reset.restype = None
         L.mdconv_set_accumulate.restype = ctypes.c_int
         L.mdconv_set_accumulate.argtypes = [ctypes.c_int]
+        L.mdconv_set_input_layout.restype = ctypes.c_int
+        L.mdconv_set_input_layout.argtypes = [ctypes.c_int]
         L.mdconv_stream_wait_weight_ready.restype = ctypes.c_int
         L.mdconv_stream_wait_weight_ready.argtypes = [ctypes.c_void_p]
         L.mdconv_stream_wait_weight_ready_on.restype = ctypes.c_int
@@ -103,6 +105,21 @@ class overwrite_grads:
 
     def __exit__(self, *exc):
         lib().mdconv_set_accumulate(self._prev)
+        return False
+
+
+class channels_last_input:
+    """Context manager: `input` of the entry points called inside is channels-last
+    (include/mdconv.h: mdconv_set_input_layout)."""
+
+    def __init__(self, on=True):
+        self._on = on
+
+    def __enter__(self):
+        self._prev = lib().mdconv_set_input_layout(1 if self._on else 0)
+
+    def __exit__(self, *exc):
+        lib().mdconv_set_input_layout(self._prev)
         return False
 
 

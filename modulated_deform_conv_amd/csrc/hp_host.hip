@@ -176,15 +176,17 @@ int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t
     tc.offset = (const char *)t.offset + (size_t)b0 * nc_off * g.S_o * 2;
     tc.mask = t.mask ? (const char *)t.mask + (size_t)b0 * nc_m * g.S_o * 2 : nullptr;
     tc.output = (char *)t.output + (size_t)b0 * g.O * g.S_o * 2;
-    if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
+    const void *xt = base + L.off_xt;
+    if (g.in_cl) xt = (const char *)t.input + (size_t)b0 * g.S_i * g.C * 2;   // already channels-last
+    else if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
     profile_mark(0, true, stream);
     // quad-contiguous gathers (hp_fwd2.hip) unless a 64-channel stage would straddle deformable groups
     static const int fwd_ver = getenv("MDCONV_HP_FWD") ? atoi(getenv("MDCONV_HP_FWD")) : 2;
     if (fwd_ver == 2 && (g.DG == 1 || (g.Cdg % 64 == 0 && hd.oranges == 1)))
-      rc = hp_forward2_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+      rc = hp_forward2_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                               (const int2 *)(base + L.off_tab), stream);
     else
-      rc = hp_forward_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+      rc = hp_forward_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                              (const int2 *)(base + L.off_tab), stream);
     profile_mark(0, false, stream);
     if (rc) return rc;
@@ -218,16 +220,18 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
     tc.grad_offset = (char *)t.grad_offset + (size_t)b0 * nc_off * g.S_o * 2;
     tc.grad_mask = t.grad_mask ? (char *)t.grad_mask + (size_t)b0 * nc_m * g.S_o * 2 : nullptr;
     int *cnt = (int *)(base + L.off_cnt), *rowptr = (int *)(base + L.off_rowptr);
-    if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
+    const void *xt = base + L.off_xt;
+    if (g.in_cl) xt = (const char *)t.input + (size_t)b0 * g.S_i * g.C * 2;   // already channels-last
+    else if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
     if ((rc = csr_zero_f32(gc, cnt, stream))) return rc;
     profile_mark(1, true, stream);
     static const int bwd_ver = getenv("MDCONV_HP_BWD") ? atoi(getenv("MDCONV_HP_BWD")) : 2;
     if (bwd_ver == 2 && g.DG <= 4 && hp_bwd2_lds_bytes(gc, hd) <= 160 * 1024)
-      rc = hp_backward2_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+      rc = hp_backward2_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                                (const int4 *)(base + L.off_tab), base + L.off_gcol,
                                (float *)(base + L.off_part), cnt, stream);
     else
-      rc = hp_backward_launch(gc, hd, dtype, tc, base + L.off_xt, base + L.off_w,
+      rc = hp_backward_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                               (const int4 *)(base + L.off_tab), base + L.off_gcol,
                               (float *)(base + L.off_part), cnt, stream);
     profile_mark(1, false, stream);

@@ -22,6 +22,7 @@ static thread_local char g_err[512] = "";
 static thread_local int g_last_path = 0;
 static thread_local int g_last_kernels = 0;
 static thread_local int g_accumulate = 1;
+static thread_local int g_input_layout = 0;   // MDCONV_LAYOUT_*
 // "grad_weight / grad_bias are final" events: one per (device, producer stream), shared by all
 // host threads (autograd runs the backward on its own worker thread), plus the most recent one per
 // device for the stream-less legacy query
@@ -186,6 +187,11 @@ static int run_forward(const mdconv_desc *d, int nd, int modulated, Tensors t, v
   if (g.with_bias && (rc = require(t.bias, "bias"))) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int path = current_path();
+  g.in_cl = g_input_layout == MDCONV_LAYOUT_CHANNELS_LAST ? 1 : 0;
+  if (g.in_cl && !(path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, false) && g.C % 32 == 0)) {
+    set_error("channels-last input is only supported by the native 16-bit kernels with C_in a multiple of 32");
+    return MDCONV_EUNSUPPORTED;
+  }
   // 16-bit tensors: native fp16 / bf16 kernels (hp_*.hip) when the shape qualifies
   if (path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, false)) {
     if ((rc = check_ws(ws, ws_bytes, hp_workspace_bytes(g, d->dtype, false)))) return rc;
@@ -231,6 +237,11 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
   hipStream_t s = (hipStream_t)stream;
   g.acc_data = g.acc_w = g_accumulate;
   const int path = current_path();
+  g.in_cl = g_input_layout == MDCONV_LAYOUT_CHANNELS_LAST ? 1 : 0;
+  if (g.in_cl && !(path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, true) && g.C % 32 == 0)) {
+    set_error("channels-last input is only supported by the native 16-bit kernels with C_in a multiple of 32");
+    return MDCONV_EUNSUPPORTED;
+  }
   if (path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, true)) {
     if ((rc = check_ws(ws, ws_bytes, hp_workspace_bytes(g, d->dtype, true)))) return rc;
     g_last_path = MDCONV_PATH_MFMA;
@@ -332,6 +343,12 @@ size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward) {
   if (hp_supported(g, d->dtype, backward != 0)) return hp_workspace_bytes(g, d->dtype, backward != 0);
   if (!mfma_supported(g, d->dtype, backward != 0)) return 0;
   return mfma_workspace_bytes(g, d->dtype, backward != 0);
+}
+
+int mdconv_set_input_layout(int layout) {
+  const int prev = g_input_layout;
+  if (layout == MDCONV_LAYOUT_NCHW || layout == MDCONV_LAYOUT_CHANNELS_LAST) g_input_layout = layout;
+  return prev;
 }
 
 int mdconv_set_accumulate(int on) {

@@ -33,6 +33,8 @@ struct Geom {
   // 0 = overwrite them (mdconv_set_accumulate); per-image gradients and weight gradients apart
   // because batch chunks after the first must add to grad_weight / grad_bias in either mode
   int acc_data, acc_w;
+  // 1 = `input` is channels-last [B, spatial..., C] (mdconv_set_input_layout; 16-bit kernels only)
+  int in_cl;
 };
 
 template <typename T> struct Acc { using type = float; };

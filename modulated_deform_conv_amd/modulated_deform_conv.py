@@ -106,7 +106,8 @@ def _make_function(nd, modulated, name):
         else:
             # the reference wrapper zero-fills and the entry points add (:53-56); here the buffers
             # are fresh, so the library is asked to write them instead (mdconv_set_accumulate)
-            grad_input, grad_offset = torch.empty_like(input), torch.empty_like(offset)
+            grad_input = torch.empty_like(input, memory_format=torch.contiguous_format)
+            grad_offset = torch.empty_like(offset)
             grad_weight, grad_bias = torch.empty_like(weight), torch.empty_like(bias)
             with _capi.overwrite_grads():
                 if modulated:

@@ -150,7 +150,7 @@ def deform_conv_backward(grad_output: torch.Tensor, input: torch.Tensor, offset:
     if mask is not None and nd == 2:
         gi, goff, gm, gw, gb = fn(input, weight, b, offset, mask, grad_output, *geo)
         return gi, goff, gm, gw, gb
-    gi, goff = torch.empty_like(input), torch.empty_like(offset)
+    gi, goff = torch.empty_like(input, memory_format=torch.contiguous_format), torch.empty_like(offset)
     gw, gb = torch.empty_like(weight), torch.empty_like(b)
     with _capi.overwrite_grads():   # fresh buffers: written, not added to
         if mask is not None:
@@ -169,7 +169,8 @@ def _(grad_output, input, offset, mask, weight, bias, stride, padding, dilation,
               deformable_groups, in_step, grad_output)
     gm = input.new_empty(0) if mask is None else torch.empty_like(mask)
     gb = input.new_empty(0) if bias is None else torch.empty_like(bias)
-    return (torch.empty_like(input), torch.empty_like(offset), gm, torch.empty_like(weight), gb)
+    return (torch.empty_like(input, memory_format=torch.contiguous_format), torch.empty_like(offset), gm,
+            torch.empty_like(weight), gb)
 
 
 def _setup_context(ctx, inputs, output):

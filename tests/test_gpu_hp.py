@@ -104,3 +104,27 @@ def test_hp_accumulate_and_overwrite():
     M.modulated_deform_conv3d_backward_cuda(x, w, b, off, m, gi, gw, gb, goff, gm, go, *geo)
     for k, g in (("grad_input", gi), ("grad_weight", gw), ("grad_bias", gb), ("grad_offset", goff), ("grad_mask", gm)):
         assert_close(k, g.float() - 1, want[k].float(), 2e-2)
+
+
+@pytest.mark.parametrize("name", ["hp_mdcn2d_c64_o96_s2", "hp_mdcn3d_c128_o128_dil2", "hp_mdcn2d_c256_o256_g32_dg4"])
+def test_channels_last_input_is_consumed_in_place(name):
+    """A channels_last / channels_last_3d fp16 input goes to the kernels as it is (no layout pass)
+    and gives the results of the contiguous input; shapes the 16-bit kernels do not take keep the
+    reference's "has to be contiguous" error."""
+    from modulated_deform_conv_amd import MDCONV_CUDA as M
+    case = {c["name"]: c for c in HP_CASES}[name]
+    t = make_inputs(case, dtype=torch.float16, device="cuda")
+    out, grads, _ = run_product(case, t, "auto")
+    fmt = torch.channels_last if t["input"].dim() == 4 else torch.channels_last_3d
+    t2 = dict(t, input=t["input"].contiguous(memory_format=fmt))
+    assert not t2["input"].is_contiguous()
+    out2, grads2, _ = run_product(case, t2, "auto")
+    assert torch.equal(out, out2)
+    for k in grads:
+        if grads[k] is not None:
+            assert_close(k, grads2[k].float(), grads[k].float(), 2e-3, 1e-2)
+    x32 = torch.randn(2, 32, 6, 6, device="cuda").contiguous(memory_format=torch.channels_last)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        M.modulated_deform_conv2d_forward_cuda(x32, torch.randn(8, 32, 3, 3, device="cuda"), x32.new_empty(0),
+                                               torch.zeros(2, 18, 6, 6, device="cuda"), torch.ones(2, 9, 6, 6, device="cuda"),
+                                               3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 64, False)

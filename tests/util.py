@@ -30,7 +30,8 @@ def run_product(case, t, path=None):
             paths.append(_capi.last_path())
         else:
             out = torch.empty_like(go)
-            gi, gw, goff = torch.zeros_like(x), torch.zeros_like(w), torch.zeros_like(off)
+            gi = torch.zeros_like(x, memory_format=torch.contiguous_format)
+            gw, goff = torch.zeros_like(w), torch.zeros_like(off)
             gb = torch.zeros_like(b)
             gm = torch.zeros_like(m) if m is not None else None
             if op == D2:

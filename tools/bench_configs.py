@@ -37,8 +37,10 @@ def run(name):
         gi, gw, gb, goff = torch.zeros_like(x), torch.zeros_like(w), torch.zeros_like(b), torch.zeros_like(off)
         bw = lambda: M.deform_conv3d_backward_cuda(x, w, b, off, gi, gw, gb, goff, go, *geo)
         ns = B * C * K * math.prod(sp)
-    elif name == "cfg2":
+    elif name.startswith("cfg2"):   # "cfg2" or "cfg2:B" (strong-scaling shards: cfg2:16, cfg2:8, cfg2:4)
         B, C, O, sp, K = 32, 256, 256, (56, 56), 9
+        if ":" in name:
+            B = int(name.split(":")[1])
         x, off, m = rn(B, C, *sp).cuda(), rn(B, 2 * K, *sp).cuda(), torch.sigmoid(rn(B, K, *sp)).cuda()
         w = ((torch.rand(O, C, 3, 3, generator=g) * 2 - 1) / math.sqrt(C * K)).cuda()
         b, go = (0.1 * rn(O)).cuda(), rn(B, O, *sp).cuda()

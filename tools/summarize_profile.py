@@ -99,7 +99,7 @@ def main(src, tag):
             f.write("| %s | %s | %.1f | %s |\n" % (short(r["Name"])[:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
         f.write("\n## HBM traffic per launch (separate --pmc passes; KiB counters -> bytes; read side x2 per the gfx950 note)\n\n"
                 "| kernel | FETCH raw MB | FETCH x2 MB | WRITE MB | total MB |\n|---|---|---|---|---|\n")
-        for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        for k, v in sorted(((k, v) for k, v in summary.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
             f.write("| %s | %.1f | %.1f | %.1f | %.1f |\n" % (k[:60], v["fetch_bytes_raw"] / 1e6, v["fetch_bytes_x2_gfx950"] / 1e6,
                                                           v["write_bytes"] / 1e6, v["hbm_bytes_per_launch"] / 1e6))
         if bench_json:
