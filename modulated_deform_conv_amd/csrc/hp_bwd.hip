@@ -179,13 +179,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 || NKS >= 16 || ND == 3) ? 
       }
     }
     if (counter && kh == 0 && live) {
-      int aidx[NP];
-      float ax[NP], ay[NP];
-      make_pairs_f<ND, float>(g, tc, tc.wl, tc.wha, 1.f, aidx, ax, ay);
-      int *cseg = cnt + ((int64_t)b * g.DG + dg) * g.S_i;
-#pragma unroll
-      for (int pi = 0; pi < NP; ++pi)
-        if (ax[pi] != 0.f || ay[pi] != 0.f) atomicAdd(cseg + aidx[pi], 1);
+      // scatter anchor of this sample (first pass of the CSR build, hp_col2im.hip)
+      SampleAnchor<ND> sa;
+      sample_anchor<ND>(g, tc, 1.f, sa);
+      if (sa.on) atomicAdd(cnt + ((int64_t)b * g.DG + dg) * hp_anchor_space(g) + sa.qa, 1);
     }
 
     __syncthreads();   // every wave is done with the previous tile's LDS tiles and partial sums

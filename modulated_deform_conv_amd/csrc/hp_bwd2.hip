@@ -95,6 +95,7 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
   const int t_hi = min(t_lo + hd.tiles_per_range, hd.ntiles);
   if (t_lo >= t_hi) return;
 
+  const int S_e = hp_anchor_space(g);              // scatter anchors per (image, deformable group)
   const int LPP = Cp / 8;                          // lanes per pixel in the gather phase (multiple of 4)
   const int LPD = g.DG == 1 ? LPP : g.Cdg / 8;     // lanes per (pixel, deformable group)
   int sub = 1;                                     // shuffle-reduced lanes: largest power of two | LPD, <= 64
@@ -189,15 +190,11 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
             if (MOD) f.old[ND] = T::ldf(grad_mask + f.msk_idx);
           }
           if (f.live) {
-            // scatter targets of this sample = its corner PAIRS with a non-zero scatter weight, keyed
-            // by the pair's first element (first pass of the CSR build, hp_col2im.hip)
-            int aidx[NP];
-            float ax[NP], ay[NP];
-            make_pairs_f<ND, float>(g, tc, tc.wl, tc.wha, 1.f, aidx, ax, ay);
-            int *cseg = cnt + seg * g.S_i;
-#pragma unroll
-            for (int pi = 0; pi < NP; ++pi)
-              if (ax[pi] != 0.f || ay[pi] != 0.f) atomicAdd(cseg + aidx[pi], 1);
+            // scatter anchor of this sample (first pass of the CSR build, hp_col2im.hip): one
+            // fire-and-forget integer atomic per sample
+            SampleAnchor<ND> sa;
+            sample_anchor<ND>(g, tc, 1.f, sa);
+            if (sa.on) atomicAdd(cnt + seg * S_e + sa.qa, 1);
           }
           advance_pixel<ND>(g, 32, nb[ps], noc[ps]);
         }

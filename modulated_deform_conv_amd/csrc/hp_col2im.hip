@@ -2,13 +2,17 @@
 //
 // Reference: the 4 / 8 atomics per sample of the gradient kernels (mdeformable_conv.cu:282-293,
 // mdeformable_conv3d.cu:341-379).  Here the data-dependent scatter is inverted once per call
-// (count [inside hp_bwd_kernel] -> scan -> fill; integer atomics only) into lists keyed by
-// (image, deformable group, input pixel): an ENTRY belongs to the first element ("anchor") of a
-// corner pair of one sample and carries (tap * S_o + output pixel, weight * mask on the anchor,
-// weight * mask on anchor + 1).  The gather then walks anchors: a group of LPD lanes (8 channels
-// each) follows one list, reads every 16-bit grad_col row [b][tap][pix][c] once per entry with
-// 16-byte loads, accumulates in fp32 (`cur` for the anchor, `nxt` for anchor + 1) and writes
-// grad_input [B, C, S_i] through an LDS transpose.  No floating-point atomics.
+// (count [inside the fused backward kernel] -> scan -> fill; integer atomics only) into lists keyed
+// by (image, deformable group, extended anchor): ONE entry per SAMPLE (tap, output pixel), keyed by
+// its low corner (hp_common.hpp: SampleAnchor) -- scattered global atomics run at 27 G/s on this
+// chip whatever their scope (tools/ubench_atomic.hip), so their NUMBER is what the build costs, and
+// keying by sample instead of by corner pair divides it by 2^(ND-1).  An entry carries
+// (tap * S_o + output pixel, weight * mask on columns cl and cl + 1, low / high weights of the
+// outer axes).  The gather walks target pixels along the last axis: a group of LPD lanes (8
+// channels each) visits, per target, the 2^(ND-1) anchor rows that can reach it, reads every 16-bit
+// grad_col row [b][tap][pix][c] once per (entry, row) with 16-byte loads, accumulates in fp32
+// (`cur` for the column, `nxt` for column + 1) and writes grad_input [B, C, S_i] through an LDS
+// transpose.  No floating-point atomics.
 #include "hp_kernels.hpp"
 
 namespace mdconv {
@@ -24,19 +28,19 @@ __global__ __launch_bounds__(256) void hp_zero_int_kernel(int *__restrict__ p, i
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
 }
 
-// exclusive scan of cnt[seg][0..S_i) -> rowptr[seg][0..S_i], one workgroup per segment
-__global__ __launch_bounds__(256) void hp_csr_scan_kernel(int S_i, const int *__restrict__ cnt,
+// exclusive scan of cnt[seg][0..S) -> rowptr[seg][0..S], one workgroup per segment
+__global__ __launch_bounds__(256) void hp_csr_scan_kernel(int S, const int *__restrict__ cnt,
                                                           int *__restrict__ rowptr) {
   __shared__ int wsum[4];
   __shared__ int carry;
   const int seg = blockIdx.x;
-  const int *c = cnt + (int64_t)seg * S_i;
-  int *rp = rowptr + (int64_t)seg * (S_i + 1);
+  const int *c = cnt + (int64_t)seg * S;
+  int *rp = rowptr + (int64_t)seg * (S + 1);
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  for (int base = 0; base < S_i; base += 256) {
+  for (int base = 0; base < S; base += 256) {
     const int i = base + threadIdx.x;
-    const int v = i < S_i ? c[i] : 0;
+    const int v = i < S ? c[i] : 0;
     int x = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -48,21 +52,22 @@ __global__ __launch_bounds__(256) void hp_csr_scan_kernel(int S_i, const int *__
     int woff = 0;
     for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) woff += wsum[k];
     const int excl = carry + woff + x - v;
-    if (i < S_i) rp[i] = excl;
+    if (i < S) rp[i] = excl;
     __syncthreads();
     if (threadIdx.x == 255) carry = excl + v;
     __syncthreads();
   }
-  if (threadIdx.x == 0) rp[S_i] = carry;
+  if (threadIdx.x == 0) rp[S] = carry;
 }
 
+// entry = 2 x int4: (src, wx, wy, rl0), (rh0, rl1, rh1, 0)
 template <int ND, bool MOD, typename T>
-__global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, const typename T::Raw *__restrict__ offset,
+__global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
+                                                          const typename T::Raw *__restrict__ offset,
                                                           const typename T::Raw *__restrict__ mask,
                                                           int *__restrict__ cursor,
                                                           const int *__restrict__ rowptr,
                                                           int4 *__restrict__ entries) {
-  constexpr int NP = 1 << (ND - 1);
   const int64_t total = (int64_t)g.B * g.DG * g.K * g.S_o;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int pix = (int)(i % g.S_o);
@@ -78,18 +83,14 @@ __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, const typename
     TapCoef<ND, float> tc;
     make_tap<ND, float>(g, oc, tcd, delta, true, tc);
     const float m = MOD ? T::ldf(mask + ((int64_t)seg * g.K + tap) * g.S_o + pix) : 1.f;
-    int aidx[NP];
-    float ax[NP], ay[NP], ux[NP], uy[NP];
-    make_pairs_f<ND, float>(g, tc, tc.wl, tc.wha, 1.f, aidx, ux, uy);   // which pairs exist (as counted)
-    make_pairs_f<ND, float>(g, tc, tc.wl, tc.wha, m, aidx, ax, ay);     // their weights, mask folded in
-#pragma unroll
-    for (int pi = 0; pi < NP; ++pi) {
-      if (ux[pi] != 0.f || uy[pi] != 0.f) {
-        const int q = aidx[pi];
-        const int pos = rowptr[(int64_t)seg * (g.S_i + 1) + q] + atomicAdd(cursor + (int64_t)seg * g.S_i + q, 1);
-        entries[(int64_t)seg * ((int64_t)g.K * g.S_o * NP) + pos] =
-            make_int4(tap * g.S_o + pix, __float_as_int(ax[pi]), __float_as_int(ay[pi]), 0);
-      }
+    SampleAnchor<ND> sa;
+    sample_anchor<ND>(g, tc, m, sa);
+    if (sa.on) {
+      const int pos = rowptr[(int64_t)seg * (S_e + 1) + sa.qa] + atomicAdd(cursor + (int64_t)seg * S_e + sa.qa, 1);
+      int4 *e = entries + ((int64_t)seg * ((int64_t)g.K * g.S_o) + pos) * 2;
+      e[0] = make_int4(tap * g.S_o + pix, __float_as_int(sa.wx), __float_as_int(sa.wy), __float_as_int(sa.rl[0]));
+      e[1] = make_int4(__float_as_int(sa.rh[0]), __float_as_int(ND == 3 ? sa.rl[ND - 2] : 0.f),
+                       __float_as_int(ND == 3 ? sa.rh[ND - 2] : 0.f), 0);
     }
   }
 }
@@ -97,16 +98,16 @@ __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, const typename
 constexpr int kRun = 8;   // targets per run
 
 // LPD lanes (8 channels each) follow one list; a wave walks 64 / LPD runs of kRun consecutive
-// anchors side by side; workgroup tile = 4 * (64 / LPD) runs.  Channel units of LPD * 8 channels
+// targets side by side; workgroup tile = 4 * (64 / LPD) runs.  Channel units of LPD * 8 channels
 // (one deformable group each when DG > 1) are processed one after the other.
 template <int ND, typename T, int LPD>
-__global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd,
+__global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S_e,
                                                         const typename T::Raw *__restrict__ gcol,
                                                         const int *__restrict__ rowptr,
                                                         const int4 *__restrict__ entries,
                                                         typename T::Raw *__restrict__ grad_input) {
   using Raw = typename T::Raw;
-  constexpr int NP = 1 << (ND - 1);
+  constexpr int L = ND - 1, NR = 1 << L;   // anchor rows that reach a target
   constexpr int NQ = 64 / LPD, RUNS = 4 * NQ, QT = RUNS * kRun;
   constexpr int CW = LPD * 8;              // channels per unit
   constexpr int UB = LPD < 8 ? LPD : 8;    // row loads in flight per step
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd,
   const int upd = (cseg + CW - 1) / CW;         // units per segment
   const int units = g.DG * upd;
   const int qs = q0 + (wave * NQ + j) * kRun;
+  const int W = g.in_sz[L], H1 = ND == 3 ? g.in_sz[1] + 1 : 1;
   for (int u = 0; u < units; ++u) {
     const int dg = u / upd;
     const int c_lo = dg * cseg + (u - dg * upd) * CW;          // first channel of the unit
@@ -130,34 +132,62 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd,
     const int c8 = c_lo + r * 8;
     const bool chan_on = c8 < c_end;
     const int seg = b * g.DG + dg;
-    const int *rp = rowptr + (int64_t)seg * (g.S_i + 1);
-    const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o * NP);
+    const int *rp = rowptr + (int64_t)seg * (S_e + 1);
+    const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * 2;
     const int c_voff = chan_on ? c8 * 2 : kHpOob;
+    // coordinates of the target of the current step (first step: qs - 1, the carry-in column)
+    int tc[ND];
+    {
+      const int a0 = max(qs - 1, 0);
+      int rem = a0;
+#pragma unroll
+      for (int a = L; a > 0; --a) { tc[a] = rem % g.in_sz[a]; rem /= g.in_sz[a]; }
+      tc[0] = rem;
+      if (qs - 1 < 0) tc[L] = -1;
+    }
     float cur[8], nxt[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) cur[k] = nxt[k] = 0.f;
     for (int step = 0; step <= kRun; ++step) {
       const int a = qs - 1 + step;
       const bool on = a >= 0 && a < g.S_i;
-      const int e0 = on ? rp[a] : 0, e1 = on ? rp[a + 1] : 0;
-      for (int base = e0; __any(base < e1); base += LPD) {
-        const int cnt = max(0, min(LPD, e1 - base));
-        const int4 mine = (r < cnt) ? ent[base + r] : make_int4(0, 0, 0, 0);   // weights 0, row 0 beyond
 #pragma unroll
-        for (int u0 = 0; u0 < LPD; u0 += UB) {
-          U4 v[UB];
-          float wx[UB], wy[UB];
+      for (int s = 0; s < NR; ++s) {
+        // anchor row s: extended low index = target + s_a on every outer axis
+        int er = 0;
 #pragma unroll
-          for (int k = 0; k < UB; ++k) {
-            const int src = __shfl(mine.x, u0 + k, LPD);
-            wx[k] = __int_as_float(__shfl(mine.y, u0 + k, LPD));
-            wy[k] = __int_as_float(__shfl(mine.z, u0 + k, LPD));
-            v[k] = buf_load4u(r_gc, src * hd.Cp * 2 + c_voff, 0);
+        for (int ax = 0; ax < L; ++ax) er = er * (g.in_sz[ax] + 1) + tc[ax] + ((s >> (L - 1 - ax)) & 1);
+        const int ea = er * W + tc[L];
+        const int e0 = on ? rp[ea] : 0, e1 = on ? rp[ea + 1] : 0;
+        for (int base = e0; __any(base < e1); base += LPD) {
+          const int cnt = max(0, min(LPD, e1 - base));
+          int src_m = 0;
+          float fx_m = 0.f, fy_m = 0.f;   // weights 0, row 0 beyond the list
+          if (r < cnt) {
+            const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
+            // target = low + 1 - s_a on axis a: s_a = 1 -> the low side (rl), 0 -> the high side (rh)
+            float rw = ((s >> (L - 1)) & 1) ? __int_as_float(ea4.w) : __int_as_float(eb4.x);
+            if (ND == 3) rw *= (s & 1) ? __int_as_float(eb4.y) : __int_as_float(eb4.z);
+            src_m = ea4.x;
+            fx_m = rw * __int_as_float(ea4.y);
+            fy_m = rw * __int_as_float(ea4.z);
           }
 #pragma unroll
-          for (int k = 0; k < UB; ++k) {
-            mac8<T>(cur, v[k], wx[k]);
-            mac8<T>(nxt, v[k], wy[k]);
+          for (int u0 = 0; u0 < LPD; u0 += UB) {
+            U4 v[UB];
+            float wx[UB], wy[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+              const int src = __shfl(src_m, u0 + k, LPD);
+              wx[k] = __shfl(fx_m, u0 + k, LPD);
+              wy[k] = __shfl(fy_m, u0 + k, LPD);
+              v[k] = buf_load4u(r_gc, src * hd.Cp * 2 + c_voff, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+              mac8<T>(cur, v[k], wx[k]);
+              mac8<T>(nxt, v[k], wy[k]);
+            }
           }
         }
       }
@@ -168,6 +198,12 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd,
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) { cur[k] = nxt[k]; nxt[k] = 0.f; }
+      // next target along the flattened image
+      if (++tc[L] == W) {
+        tc[L] = 0;
+        if (ND == 3) { if (++tc[1] == g.in_sz[1]) { tc[1] = 0; ++tc[0]; } }
+        else ++tc[0];
+      }
     }
     __syncthreads();
     // transpose out: consecutive threads -> consecutive q of one channel
@@ -190,11 +226,12 @@ int launch_col2im(const Geom &g, const HpDims &hd, const Tensors &t, const void 
   using Raw = typename T::Raw;
   const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;
   const int lanes = (cseg + 7) / 8;
+  const int S_e = hp_anchor_space(g);
 #define HP_C2I(LPD)                                                                              \
   do {                                                                                           \
     const int qt = 4 * (64 / LPD) * kRun;                                                        \
     hipLaunchKernelGGL((hp_col2im_kernel<ND, T, LPD>), dim3(g.B * ((g.S_i + qt - 1) / qt)),      \
-                       dim3(256), 0, stream, g, hd, (const Raw *)gcol, rowptr,                   \
+                       dim3(256), 0, stream, g, hd, S_e, (const Raw *)gcol, rowptr,              \
                        (const int4 *)entries, (Raw *)t.grad_input);                              \
   } while (0)
   if (lanes <= 4) HP_C2I(4);
@@ -208,17 +245,22 @@ int launch_col2im(const Geom &g, const HpDims &hd, const Tensors &t, const void 
 
 }  // namespace
 
+int hp_csr_zero(const Geom &g, int *cnt, hipStream_t stream) {
+  const int64_t cnt_n = (int64_t)g.B * g.DG * hp_anchor_space(g);
+  hipLaunchKernelGGL(hp_zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
+  return check_launch("hp_zero_cnt");
+}
+
 int hp_csr_build(const Geom &g, int dtype, const Tensors &t, int *cnt, int *rowptr, void *entries,
                  hipStream_t stream) {
   const int64_t samples = (int64_t)g.B * g.DG * g.K * g.S_o;
-  const int64_t cnt_n = (int64_t)g.B * g.DG * g.S_i;
+  const int S_e = hp_anchor_space(g);
   int rc;
-  hipLaunchKernelGGL(hp_csr_scan_kernel, dim3(g.B * g.DG), dim3(256), 0, stream, g.S_i, cnt, rowptr);
+  hipLaunchKernelGGL(hp_csr_scan_kernel, dim3(g.B * g.DG), dim3(256), 0, stream, S_e, cnt, rowptr);
   if ((rc = check_launch("hp_csr_scan"))) return rc;
-  hipLaunchKernelGGL(hp_zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
-  if ((rc = check_launch("hp_zero_cnt"))) return rc;
+  if ((rc = hp_csr_zero(g, cnt, stream))) return rc;
 #define HP_CSR(ND, MOD, T)                                                                        \
-  hipLaunchKernelGGL((hp_csr_fill_kernel<ND, MOD, T>), dim3(grid_for(samples)), dim3(256), 0, stream, g, \
+  hipLaunchKernelGGL((hp_csr_fill_kernel<ND, MOD, T>), dim3(grid_for(samples)), dim3(256), 0, stream, g, S_e, \
                      (const typename T::Raw *)t.offset, (const typename T::Raw *)t.mask, cnt, rowptr,    \
                      (int4 *)entries)
 #define HP_CSR_T(T)                                                                               \

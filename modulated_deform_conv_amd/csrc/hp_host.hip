@@ -73,16 +73,17 @@ FwdLayout fwd_layout(const Geom &gc, const HpDims &hd) {
 
 BwdLayout bwd_layout(const Geom &gc, const HpDims &hd) {
   BwdLayout L;
-  const int np = 1 << (gc.nd - 1);
   size_t off = 0;
   L.off_xt = off;   off += align_up((size_t)gc.B * gc.S_i * hd.Cp * 2);
   L.off_w = off;    off += align_up((size_t)gc.K * hd.cblks * hd.nks * 1024);
   L.off_tab = off;  off += align_up((size_t)hd.cblks * sizeof(int4));
   L.off_gcol = off; off += align_up((size_t)gc.B * gc.K * gc.S_o * hd.Cp * 2);
   L.off_part = off; off += align_up((size_t)gc.K * hd.ranges * hd.cblks * hd.MB2 * 4096);
-  L.off_cnt = off;  off += align_up((size_t)gc.B * gc.DG * gc.S_i * sizeof(int));
-  L.off_rowptr = off; off += align_up((size_t)gc.B * gc.DG * (gc.S_i + 1) * sizeof(int));
-  L.off_entries = off; off += align_up((size_t)gc.B * gc.DG * gc.K * gc.S_o * np * 16);
+  // scatter lists: one 32-byte entry per sample, keyed by its extended anchor (hp_col2im.hip)
+  const size_t S_e = (size_t)hp_anchor_space(gc);
+  L.off_cnt = off;  off += align_up((size_t)gc.B * gc.DG * S_e * sizeof(int));
+  L.off_rowptr = off; off += align_up((size_t)gc.B * gc.DG * (S_e + 1) * sizeof(int));
+  L.off_entries = off; off += align_up((size_t)gc.B * gc.DG * gc.K * gc.S_o * 32);
   L.total = off;
   return L;
 }
@@ -223,7 +224,7 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
     const void *xt = base + L.off_xt;
     if (g.in_cl) xt = (const char *)t.input + (size_t)b0 * g.S_i * g.C * 2;   // already channels-last
     else if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
-    if ((rc = csr_zero_f32(gc, cnt, stream))) return rc;
+    if ((rc = hp_csr_zero(gc, cnt, stream))) return rc;
     profile_mark(1, true, stream);
     static const int bwd_ver = getenv("MDCONV_HP_BWD") ? atoi(getenv("MDCONV_HP_BWD")) : 2;
     if (bwd_ver == 2 && g.DG <= 4 && hp_bwd2_lds_bytes(gc, hd) <= 160 * 1024)

@@ -41,7 +41,8 @@ int hp_backward2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensor
                         const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                         hipStream_t stream);
 
-// hp_col2im.hip: inverse scatter map (count inside hp_bwd) + gather
+// hp_col2im.hip: inverse scatter map (counting pass inside the fused backward kernel) + gather
+int hp_csr_zero(const Geom &g, int *cnt, hipStream_t stream);
 int hp_csr_build(const Geom &g, int dtype, const Tensors &t, int *cnt, int *rowptr, void *entries,
                  hipStream_t stream);
 int hp_col2im(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *gcol,

@@ -78,6 +78,7 @@ template <int ND, typename A> struct TapCoef {
   int last_lc;   // clamped low coordinate on the last (contiguous) axis
   bool inside;   // -1 < p_a < size_a on every axis
   bool vl[ND], vh[ND];   // the low / high side lies inside the image (the reference reads it)
+  int low[ND];           // floor of the (clamped to [-2, size+1]) coordinate, NOT clamped to the image
 };
 
 // Decompose a flattened output pixel index into per-axis coordinates.
@@ -131,6 +132,7 @@ __device__ __forceinline__ void make_tap(const Geom &g, const int *o, const int 
     const bool vh_atom = vh && (!g.atom_eps || big);
     tc.vl[a] = vl;
     tc.vh[a] = vh_load;
+    tc.low[a] = low;
     tc.wl[a] = vl ? (A)1 - d : (A)0;
     tc.wh[a] = vh_load ? d : (A)0;
     tc.wha[a] = vh_atom ? d : (A)0;
