@@ -99,6 +99,15 @@ HpDims hp_dims(const Geom &g) {
   hd.Op = (g.O + 31) / 32 * 32;
   hd.oblks = hd.Op / 32;
   hd.MB = hd.oblks >= 5 ? 8 : (hd.oblks >= 3 ? 4 : hd.oblks);
+  if (g.G > 1) {
+    // conv groups: a workgroup row only needs the output channels one 64-channel K stage can
+    // reach (cfg3: 64 channels = 8 groups = 64 outputs), so rows are made that narrow -- more,
+    // lighter workgroups (fewer accumulators, one K stage per tap) instead of one row that walks
+    // every input channel with 7 of its 8 output blocks idle
+    const int reach = (64 / g.Cg < 1 ? 1 : 64 / g.Cg) * g.Og;   // outputs fed by 64 input channels
+    int mb = pow2_ceil((reach + 31) / 32);
+    if (mb < hd.MB) hd.MB = mb;
+  }
   hd.oranges = (hd.oblks + hd.MB - 1) / hd.MB;
   hd.fwd_nmax = 1;
   for (int orange = 0; orange < hd.oranges; ++orange) {
@@ -157,6 +166,20 @@ size_t hp_workspace_bytes(const Geom &g, int dtype, bool backward) {
   return backward ? bwd_layout(gc, hd).total : fwd_layout(gc, hd).total;
 }
 
+// hp_fwd2 with deformable groups: every workgroup row's channel range must start on a group
+// boundary (its stages are numbered from there)
+static bool fwd2_rows_align(const Geom &g, const HpDims &hd) {
+  if (hd.oranges == 1) return true;
+  if (g.G == 1) return false;
+  for (int r = 1; r < hd.oranges; ++r) {
+    const int o_first = r * hd.MB * 32;
+    if (o_first % g.Og) return false;                      // rows start on a conv-group boundary
+    const int c_first = (o_first / g.Og) * g.Cg;
+    if (c_first % g.Cdg || c_first % 64) return false;     // ... which is a deformable-group / stage boundary
+  }
+  return true;
+}
+
 int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
   const int Bc = chunk_batch(g, hp_dims(g), false);
   if (Bc <= 0) { set_error("hp_forward: no plan"); return MDCONV_EUNSUPPORTED; }
@@ -183,7 +206,7 @@ int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t
     profile_mark(0, true, stream);
     // quad-contiguous gathers (hp_fwd2.hip) unless a 64-channel stage would straddle deformable groups
     static const int fwd_ver = getenv("MDCONV_HP_FWD") ? atoi(getenv("MDCONV_HP_FWD")) : 2;
-    if (fwd_ver == 2 && (g.DG == 1 || (g.Cdg % 64 == 0 && hd.oranges == 1)))
+    if (fwd_ver == 2 && (g.DG == 1 || (g.Cdg % 64 == 0 && fwd2_rows_align(g, hd))))
       rc = hp_forward2_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                               (const int2 *)(base + L.off_tab), stream);
     else
