@@ -128,47 +128,6 @@ __device__ __forceinline__ void hp_corners(const TapCoef<ND, float> &tc, HpCorne
   }
 }
 
-// Scatter anchor of a SAMPLE for the inverted scatter map (hp_col2im.hip).  One list entry per
-// sample instead of one per corner pair (2^(ND-1) times fewer entries and integer atomics): the
-// entry is keyed by the sample's low corner in an EXTENDED index space -- low + 1 in [0, size] on
-// every axis but the last, so that "target = low" and "target = low + 1" need no border cases --
-// and by the pair column cl = min(low, size - 2) on the last axis (make_pairs_f); it carries the
-// two column weights (mask folded in) and the low / high weights of the other axes.
-template <int ND> struct SampleAnchor {
-  int qa;                  // extended anchor index inside one (image, deformable group) segment
-  float wx, wy;            // scatter weights (x mask) on columns cl and cl + 1
-  float rl[ND - 1], rh[ND - 1];   // low / high scatter weights of the outer axes
-  bool on;                 // the sample scatters anywhere at all (decided WITHOUT the mask)
-};
-__host__ __device__ inline int hp_anchor_space(const Geom &g) {
-  int s = g.in_sz[g.nd - 1];
-  for (int a = 0; a < g.nd - 1; ++a) s *= g.in_sz[a] + 1;
-  return s;
-}
-template <int ND>
-__device__ __forceinline__ void sample_anchor(const Geom &g, const TapCoef<ND, float> &tc, float m,
-                                              SampleAnchor<ND> &sa) {
-  constexpr int L = ND - 1;
-  const int lc = tc.last_lc, hc = lc + tc.delta[L];   // the last axis has element stride 1
-  const int cl = min(lc, g.in_sz[L] - 2);
-  const float ux = (lc == cl ? tc.wl[L] : 0.f) + (hc == cl ? tc.wha[L] : 0.f);
-  const float uy = (lc == cl + 1 ? tc.wl[L] : 0.f) + (hc == cl + 1 ? tc.wha[L] : 0.f);
-  bool on = ux != 0.f || uy != 0.f;
-  int q = 0;
-#pragma unroll
-  for (int a = 0; a < L; ++a) {
-    const int e = tc.low[a] + 1;
-    on = on && e >= 0 && e <= g.in_sz[a] && (tc.wl[a] != 0.f || tc.wha[a] != 0.f);
-    q = q * (g.in_sz[a] + 1) + min(max(e, 0), g.in_sz[a]);
-    sa.rl[a] = tc.wl[a];
-    sa.rh[a] = tc.wha[a];
-  }
-  sa.qa = q * g.in_sz[L] + cl;
-  sa.wx = ux * m;
-  sa.wy = uy * m;
-  sa.on = on;
-}
-
 // ---- dimensions / workspace of the 16-bit path ----
 struct HpDims {
   int Cp;           // C_in rounded up to 32: channel pitch of xt and of the grad_col rows

@@ -300,7 +300,13 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     int pidx[NP];
     float px[NP], py[NP];
     make_pairs<ND, float>(g, tc, 1.f, pidx, px, py);
-    if (count && kh == 0 && pp.live) {
+    if (ND == 3 && count && kh == 0 && pp.live) {
+      // 3-D: one list entry per sample, keyed by its low corner (mfma_csr3d.hip): one atomic
+      SampleAnchor<ND> sa;
+      sample_anchor<ND>(g, tc, 1.f, sa);
+      if (sa.on) atomicAdd(cnt + ((int64_t)pp.b * g.DG + dgp) * bd.S_e + sa.qa, 1);
+    }
+    if (ND == 2 && count && kh == 0 && pp.live) {
       // scatter targets of this sample = its corner PAIRS with a non-zero scatter weight, keyed by
       // the pair's first element (the "anchor"; the col2im gather walks anchors, see below)
       int aidx[NP];
@@ -1030,34 +1036,35 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
   return check_launch("mfma_bwd_data");
 }
 
-int csr_zero_f32(const Geom &g, int *cnt, hipStream_t stream) {
-  const int64_t cnt_n = (int64_t)g.B * g.DG * g.S_i;
+int csr_zero_f32(const Geom &g, const BwdDims &bd, int *cnt, hipStream_t stream) {
+  const int64_t cnt_n = (int64_t)g.B * g.DG * bd.S_e;
   hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
   return check_launch("zero_cnt");
 }
 
 // second half of the CSR build (the counting pass ran inside GEMM-1): scan -> fill
-int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
-                  hipStream_t stream) {
+int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, int *rowptr,
+                  void *entries, hipStream_t stream) {
   const int64_t samples = (int64_t)g.B * g.DG * g.K * g.S_o;
-  const int64_t cnt_n = (int64_t)g.B * g.DG * g.S_i;
+  const int64_t cnt_n = (int64_t)g.B * g.DG * bd.S_e;
   int rc;
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B * g.DG), dim3(256), 0, stream, g.S_i, cnt, rowptr);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B * g.DG), dim3(256), 0, stream, bd.S_e, cnt, rowptr);
   if ((rc = check_launch("csr_scan"))) return rc;
   hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
   if ((rc = check_launch("zero_cnt"))) return rc;
+  if (bd.sample_keyed) return csr_fill3d_f32(g, bd, t, cnt, rowptr, entries, stream);
 #define LAUNCH_CSR(ND, MOD)                                                                     \
   hipLaunchKernelGGL((csr_fill_kernel<ND, MOD>), dim3(grid_for(samples)), dim3(256), 0, stream,  \
                      g, (const float *)t.offset, (const float *)t.mask, cnt, rowptr,            \
                      (int4 *)entries)
-  if (g.nd == 2) { if (g.modulated) LAUNCH_CSR(2, true); else LAUNCH_CSR(2, false); }
-  else { if (g.modulated) LAUNCH_CSR(3, true); else LAUNCH_CSR(3, false); }
+  if (g.modulated) LAUNCH_CSR(2, true); else LAUNCH_CSR(2, false);   // 3-D: csr_fill3d_f32 above
 #undef LAUNCH_CSR
   return check_launch("csr_fill");
 }
 
-int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *rowptr,
-               const void *entries, hipStream_t stream) {
+int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol,
+               const int *rowptr, const void *entries, hipStream_t stream) {
+  if (bd.sample_keyed) return col2im3d_f32(g, bd, t, gcol, rowptr, entries, stream);
   const int qtiles = (g.S_i + 31) / 32;
   const dim3 grid(g.B * qtiles, 1);
 #define LAUNCH_GG(ND, LPD)                                                                      \
@@ -1070,19 +1077,17 @@ int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *ro
                        dim3(256), 0, stream, g, gcol, rowptr, (const int4 *)entries,            \
                        (float *)t.grad_input);                                                  \
   } while (0)
+  // (2-D only from here: the pair-keyed lists)
   if (g.DG == 1 && g.C == 64) {
-    if (g.nd == 2) LAUNCH_NARROW(2, 16); else LAUNCH_NARROW(3, 16);
+    LAUNCH_NARROW(2, 16);
   } else if (g.DG == 1 && g.C == 128) {
-    if (g.nd == 2) LAUNCH_NARROW(2, 32); else LAUNCH_NARROW(3, 32);
+    LAUNCH_NARROW(2, 32);
   } else if (g.DG > 1 && g.Cdg == 64) {
-    if (g.nd == 2) LAUNCH_GG(2, 16); else LAUNCH_GG(3, 16);
+    LAUNCH_GG(2, 16);
   } else if (g.DG > 1 && g.Cdg == 128) {
-    if (g.nd == 2) LAUNCH_GG(2, 32); else LAUNCH_GG(3, 32);
-  } else if (g.nd == 2) {
-    hipLaunchKernelGGL((col2im_gather_kernel<2>), grid, dim3(256), 0, stream, g, gcol, rowptr,
-                       (const int4 *)entries, (float *)t.grad_input);
+    LAUNCH_GG(2, 32);
   } else {
-    hipLaunchKernelGGL((col2im_gather_kernel<3>), grid, dim3(256), 0, stream, g, gcol, rowptr,
+    hipLaunchKernelGGL((col2im_gather_kernel<2>), grid, dim3(256), 0, stream, g, gcol, rowptr,
                        (const int4 *)entries, (float *)t.grad_input);
   }
 #undef LAUNCH_GG

@@ -130,9 +130,13 @@ BwdDims bwd_dims(const Geom &g) {
   bd.off_table = off; off += align_up((size_t)g.DG * g.K * bd.Np * 2 * (1 << g.nd) * sizeof(int));
   bd.off_part = off; off += align_up((size_t)bd.splits * g.K * bd.OgpB * bd.Cp * sizeof(float));
   bd.off_gcol = off; off += align_up((size_t)g.B * g.C * g.K * g.S_o * sizeof(float));
-  bd.off_cnt = off;  off += align_up((size_t)g.B * g.DG * g.S_i * sizeof(int));
-  bd.off_rowptr = off; off += align_up((size_t)g.B * g.DG * (g.S_i + 1) * sizeof(int));
-  bd.off_entries = off; off += align_up((size_t)g.B * g.DG * g.K * g.S_o * (nc / 2) * 16);
+  // scatter lists: 2-D one entry per corner pair keyed by the pair's first pixel; 3-D one entry per
+  // sample keyed by its low corner in the extended anchor space (4x fewer entries and atomics)
+  bd.sample_keyed = g.nd == 3 ? 1 : 0;
+  bd.S_e = bd.sample_keyed ? hp_anchor_space(g) : g.S_i;
+  bd.off_cnt = off;  off += align_up((size_t)g.B * g.DG * bd.S_e * sizeof(int));
+  bd.off_rowptr = off; off += align_up((size_t)g.B * g.DG * (bd.S_e + 1) * sizeof(int));
+  bd.off_entries = off; off += align_up((size_t)g.B * g.DG * g.K * g.S_o * (bd.sample_keyed ? 32 : (nc / 2) * 16));
   bd.bias_tiles = (g.N + 32 * (4 / bd.waves_c) - 1) / (32 * (4 / bd.waves_c));
   bd.off_bias = off; off += align_up((size_t)bd.bias_tiles * g.O * sizeof(float));
   bd.off_xt = off;   off += bd.cl ? align_up((size_t)g.B * g.S_i * g.C * sizeof(float)) : 0;
@@ -198,7 +202,7 @@ bool make_plan(const Geom &g, int dtype, bool backward, Plan *p) {
     const BwdDims b1 = bwd_dims(chunk_geom(g, 1));
     const size_t per_ga = (size_t)g.S_o * b1.OgpB * 4;
     const size_t per_tab = (size_t)g.DG * g.K * g.S_o * 2 * (1 << g.nd) * 4;
-    const size_t per_ent = (size_t)g.DG * g.K * g.S_o * (1 << (g.nd - 1)) * 16;
+    const size_t per_ent = (size_t)g.DG * g.K * g.S_o * 32;   // 2 pair entries (2-D) or 1 sample entry (3-D)
     if (per_col > per) per = per_col;
     if (per_ga > per) per = per_ga;
     if (per_tab > per) per = per_tab;
@@ -291,7 +295,7 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   void *entries = base + bd.off_entries;
   int rc;
   if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
-  if ((rc = csr_zero_f32(g, cnt, stream))) return rc;
+  if ((rc = csr_zero_f32(g, bd, cnt, stream))) return rc;
   float *bias_part = g.with_bias ? (float *)(base + bd.off_bias) : nullptr;
   // channels-last copy of the input for the 3-D gathers of GEMM-1's drain and of GEMM-2
   float *xt = bd.cl ? (float *)(base + bd.off_xt) : nullptr;
@@ -302,8 +306,8 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   if (rc) return rc;
   if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
   if (weights_final && (rc = record_weight_ready(stream))) return rc;
-  if ((rc = csr_build_f32(g, t, cnt, rowptr, entries, stream))) return rc;
-  return col2im_f32(g, t, gcol, rowptr, entries, stream);
+  if ((rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, stream))) return rc;
+  return col2im_f32(g, bd, t, gcol, rowptr, entries, stream);
 }
 
 }  // namespace

@@ -81,6 +81,8 @@ struct BwdDims {
   int waves_c, cblks_q; // GEMM-1: waves along channels (4/2/1), 32-channel blocks of wq
   // workspace byte offsets
   int bias_tiles;       // pixel tiles of GEMM-1 = rows of the grad_bias partial sums
+  int sample_keyed;     // scatter lists: 1 = one entry per SAMPLE (3-D, mfma_csr3d.hip), 0 = per corner pair
+  int S_e;              // list heads per (image, deformable group): anchor space (3-D) or S_i
   size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
       off_xt, off_end;
 };
@@ -115,10 +117,15 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, float *ga, float *bias_part, int *cnt, int *table,
                       const float *xt, hipStream_t stream);
-int csr_zero_f32(const Geom &g, int *cnt, hipStream_t stream);
-int csr_build_f32(const Geom &g, const Tensors &t, int *cnt, int *rowptr, void *entries,
-                  hipStream_t stream);
-int col2im_f32(const Geom &g, const Tensors &t, const float *gcol, const int *rowptr,
-               const void *entries, hipStream_t stream);
+int csr_zero_f32(const Geom &g, const BwdDims &bd, int *cnt, hipStream_t stream);
+int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, int *rowptr,
+                  void *entries, hipStream_t stream);
+int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol,
+               const int *rowptr, const void *entries, hipStream_t stream);
+// 3-D: scatter lists keyed by sample (mfma_csr3d.hip)
+int csr_fill3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cursor,
+                   const int *rowptr, void *entries, hipStream_t stream);
+int col2im3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol,
+                 const int *rowptr, const void *entries, hipStream_t stream);
 
 }  // namespace mdconv

@@ -10,7 +10,7 @@ timeout 250 rocprofv3 --pmc $1 --output-format csv -d $D -o p -- python $ROOT/to
 python3 - <<PY
 import csv, collections, re
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
-pref="${3:-hp_}"
+pref="${3-hp_}"
 for r in csv.DictReader(open("$D/p_counter_collection.csv")):
     k=re.sub(r"\(.*","",r["Kernel_Name"].replace("void ","").replace("mdconv::(anonymous namespace)::","").replace("mdconv::",""))
     if k.startswith(pref): acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
