@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   constexpr int BNP = 32 * WAVES_P;        // pixels per tile
   constexpr int RB = ND == 2 ? 8 : 4;      // accumulator rows per drain batch
   constexpr int NBATCH = MB * 16 / RB;
+  constexpr int SUB = 32 / NBATCH / 4;     // CL drain: quads of pixels per batch
   constexpr int kOob = 0x7ffffff0;         // out-of-range buffer offset: loads give 0, stores drop
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int T_o = bd.ochunks;              // multiple of 4
@@ -162,6 +163,17 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   const rsrc_t r_gc = make_rsrc(gcol, (size_t)g.B * g.C * g.K * g.S_o * 4);
   const int a_lane = lane * 16;
   const float *Bb = Gs + (wp * 32 + (lane & 31)) * gpitch + 4 * kh;
+  // CL drain (line-wide gathers, see `gather`): per wave a parked-accumulator tile Pk[32][kPkPitch]
+  // ([pixel][channel]), and per pixel a state row St[kStRow]: 2^ND corner byte offsets into xt, the
+  // grad_col row offset, 2^ND reduced corner sums
+  constexpr int kPkPitch = 68, kStRow = 2 * NC + 4;
+  float *Pk = red + bd.red_floats + wave * (32 * kPkPitch);
+  int *St = reinterpret_cast<int *>(red + bd.red_floats + 4 * 32 * kPkPitch) + wave * (32 * kStRow);
+  const int gl_p = lane >> 4, gl_q = lane & 15;   // gather role: pixel of the quad-of-pixels, channel quad
+  if (CL) {
+    for (int i = lane; i < 32 * kPkPitch; i += 64) Pk[i] = 0.f;
+    for (int i = lane; i < 32 * kStRow; i += 64) St[i] = kOob;
+  }
 
   // K range of a pass: with conv groups only the o-chunks of the groups that own this wave's 64
   // channels carry non-zero weights (quads of 4 chunks = 64 output channels)
@@ -360,6 +372,13 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       }
     }
     gc_voff = pp.live ? ((((pp.b * g.K + tapp) * g.S_o + pp.pix) * g.C) + 4 * kh) * 4 : kOob;
+    if (CL && kh == 0) {
+      int *st = St + lane * kStRow;
+#pragma unroll
+      for (int c4 = 0; c4 < NC; c4 += 4)
+        *reinterpret_cast<int4 *>(st + c4) = make_int4(voffc[c4], voffc[c4 + 1], voffc[c4 + 2], voffc[c4 + 3]);
+      st[NC] = gc_voff;
+    }
     // S[e] = sum over this lane's channels of grad_col * (element e of the corner pairs).  The
     // corner weights and their derivatives do not depend on the channel, so the drain costs
     // 2^ND FMAs per channel and grad_mask / grad_offset are recovered from S once per tap:
@@ -375,15 +394,25 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   auto gather = [&](int q, int cbase_p, Batch &v) {
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
     if (CL) {
+      // Line-wide gathers: batch q covers the pixels [q * PPB, (q + 1) * PPB) of the wave's 32 for
+      // ALL 64 channels; lane = (pixel gl_p of a quad of pixels, channel quad gl_q), so the 16 lanes
+      // of a pixel read one 256-byte segment of xt per corner.  (With lane = pixel, the accumulator
+      // layout, every lane touched its own cache line: 55 L1 accesses per load instruction at cfg4,
+      // the texture path busy 97 % of the kernel -- profiles/r02_other_configs.md.)
+      const bool chan_ok = cbase_p + 4 * gl_q < g.C;
 #pragma unroll
-      for (int gq = 0; gq < RB / 4; ++gq) {
-        const int cu4 = cbase_p + mb * 32 + 8 * ((r0 >> 2) + gq);   // + 4*kh is in the voffset
-        const int cs = min(cu4, g.C - 8) * 4;
+      for (int sp = 0; sp < SUB; ++sp) {
+        const int *st = St + ((q * SUB + sp) * 4 + gl_p) * kStRow;
 #pragma unroll
-        for (int ci = 0; ci < NC; ++ci) {
-          const float4 x = buf_load4(r_in, voffc[ci], cs);
-          float *d = v.f + (gq * NC + ci) * 4;
-          d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        for (int c4 = 0; c4 < NC; c4 += 4) {
+          const int4 o = *reinterpret_cast<const int4 *>(st + c4);
+          const int ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 x = buf_load4(r_in, chan_ok ? ov[k] + 16 * gl_q : kOob, cbase_p * 4);
+            float *d = v.f + ((sp * NC) + c4 + k) * 4;
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+          }
         }
       }
     } else {
@@ -402,6 +431,37 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     }
   };
   auto consume = [&](int q, int cbase_p, const Batch &v) {
+    if (CL) {
+      const bool chan_ok = cbase_p + 4 * gl_q < g.C;
+#pragma unroll
+      for (int sp = 0; sp < SUB; ++sp) {
+        const int pxl = (q * SUB + sp) * 4 + gl_p;
+        int *st = St + pxl * kStRow;
+        const float4 gc = *reinterpret_cast<const float4 *>(Pk + pxl * kPkPitch + 4 * gl_q);
+        // grad_col row piece: the 16 lanes of a pixel store 256 contiguous bytes
+        buf_store4(r_gc, chan_ok ? st[NC] + 16 * gl_q : kOob, cbase_p * 4, gc.x, gc.y, gc.z, gc.w);
+        float s[NC];
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+          const float *x = v.f + (sp * NC + ci) * 4;
+          s[ci] = fmaf(gc.w, x[3], fmaf(gc.z, x[2], fmaf(gc.y, x[1], gc.x * x[0])));
+        }
+        // sum over the 16 lanes (64 channels) of the pixel: rotations inside the DPP row
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+          s[ci] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s[ci]), 0x128, 0xf, 0xf, false));
+          s[ci] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s[ci]), 0x124, 0xf, 0xf, false));
+          s[ci] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s[ci]), 0x122, 0xf, 0xf, false));
+          s[ci] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s[ci]), 0x121, 0xf, 0xf, false));
+        }
+        if (gl_q == 0) {
+#pragma unroll
+          for (int c4 = 0; c4 < NC; c4 += 4)
+            *reinterpret_cast<float4 *>(st + NC + 4 + c4) = make_float4(s[c4], s[c4 + 1], s[c4 + 2], s[c4 + 3]);
+        }
+      }
+      return;
+    }
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
     // grad_col[b][tap][pix][c]: rows r0+4g .. r0+4g+3 are 4 consecutive channels.  Dead lanes
     // and padded channels store to an out-of-range offset, which the bounds check drops.
@@ -419,12 +479,39 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci) {
         // element ci of the corner pairs = corner ci (pair ci/2, first / second element)
-        const float x = CL ? v.f[((rr >> 2) * NC + ci) * 4 + (rr & 3)] : v.f[(rr * NP + (ci >> 1)) * 2 + (ci & 1)];
+        const float x = v.f[(rr * NP + (ci >> 1)) * 2 + (ci & 1)];
         S[ci] = fmaf(gc, x, S[ci]);
       }
     }
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) asm volatile("" : "+v"(S[ci]));   // pin the updates here
+  };
+
+  // CL: after the last batch, the owner lanes of a pixel pick up its reduced corner sums
+  auto collect = [&]() {
+    if (CL) {
+      const float *sr = reinterpret_cast<const float *>(St + (lane & 31) * kStRow + NC + 4);
+#pragma unroll
+      for (int c4 = 0; c4 < NC; c4 += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(sr + c4);
+        S[c4] += t.x; S[c4 + 1] += t.y; S[c4 + 2] += t.z; S[c4 + 3] += t.w;
+      }
+    }
+  };
+  // park the accumulators of the finished K loop: registers (NCHW drain) or the LDS tile (CL)
+  auto park = [&]() {
+    if (CL) {
+      float *dst = Pk + (lane & 31) * kPkPitch + 4 * kh;
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          *reinterpret_cast<float4 *>(dst + i * 32 + 8 * rq) =
+              make_float4(acc[i][4 * rq], acc[i][4 * rq + 1], acc[i][4 * rq + 2], acc[i][4 * rq + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) accp[i] = acc[i];
+    }
   };
 
   // ---- tap `tapp` of the parked tile is complete for this wave's channels: reduce, park in
@@ -442,9 +529,28 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       goff[a] *= mg;
     }
     // reduce over channels: the two half-waves here, the blocks of a group at the flush
+    if (!CL) {   // (CL: both half-waves already hold the sums over all 64 channels)
 #pragma unroll
-    for (int a = 0; a < ND; ++a) goff[a] += __shfl_xor(goff[a], 32, 64);
-    gm += __shfl_xor(gm, 32, 64);
+      for (int a = 0; a < ND; ++a) goff[a] += __shfl_xor(goff[a], 32, 64);
+      gm += __shfl_xor(gm, 32, 64);
+    }
+    if (bd.red_floats == 0) {
+      // one wave owns all channels of its pixels (C_in <= 64, one deformable group): nothing to
+      // reduce across waves or passes, the owner lanes write straight to global memory
+      if (kh == 0 && pp.live) {
+        const int64_t ob = ((int64_t)pp.b * (ND * g.K) + ND * tapp) * g.S_o + pp.pix;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          float *dst = grad_offset + ob + (int64_t)a * g.S_o;
+          *dst = g.acc_data ? *dst + goff[a] : goff[a];
+        }
+        if (MOD) {
+          float *dst = grad_mask + ((int64_t)pp.b * g.K + tapp) * g.S_o + pp.pix;
+          *dst = g.acc_data ? *dst + gm : gm;
+        }
+      }
+      return;
+    }
     const int slot = tapp % kTapGroup;
     if (kh == 0) {
       float *rp = red + ((slot * nblk + blk) * (ND + 1)) * BNP + wp * 32 + lane;
@@ -585,10 +691,10 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     }
     // the parked tap is complete after its last pass (per block: after every pass); its group is
     // flushed at a group / tile end
+    collect();
     if (it > 0 && (passp == passes - 1 || per_block))
       finish_tap(tapp, per_block ? passp * WAVES_C + wc : wc, passp == passes - 1, false);
-#pragma unroll
-    for (int i = 0; i < MB; ++i) accp[i] = acc[i];
+    park();
     pp = pc;
     tapp = tap;
     passp = pass;
@@ -615,6 +721,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
+    collect();
     finish_tap(tapp, per_block ? passp * WAVES_C + wc : wc, true, true);
   }
 }
@@ -978,8 +1085,10 @@ int num_cus() {
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
   const int bnp = 32 * (4 / bd.waves_c);
   const int passes = bd.cblks_q / (2 * bd.waves_c);
-  const size_t red = (size_t)kTapGroup * 128 * (g.DG > 1 ? passes : 1) * (g.nd + 1);
-  return ((size_t)bnp * (bd.ochunks * 16 + 4) + red) * sizeof(float);
+  const size_t red = (size_t)bd.red_floats;
+  // channels-last drain: parked accumulators [4 waves][32][68] + state rows [4 waves][32][2^nd * 2 + 4]
+  const size_t cl = bd.cl ? (size_t)4 * 32 * 68 + (size_t)4 * 32 * (2 * (1 << g.nd) + 4) : 0;
+  return ((size_t)bnp * (bd.ochunks * 16 + 4) + red + cl) * sizeof(float);
 }
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,

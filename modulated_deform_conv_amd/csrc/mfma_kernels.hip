@@ -123,6 +123,9 @@ BwdDims bwd_dims(const Geom &g) {
   bd.ochunks = (g.O + 63) / 64 * 4;   // K loop of GEMM-1 is unrolled 4x
   bd.waves_c = g.C > 128 ? 4 : (g.C > 64 ? 2 : 1);
   bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
+  // [tap group of 9][64-channel blocks to reduce][nd + 1][pixels of the tile], see mfma_bwd_data.hip
+  bd.red_floats = 9 * 128 * (g.DG > 1 ? bd.cblks_q / (2 * bd.waves_c) : 1) * (g.nd + 1);
+  if (g.DG == 1 && bd.waves_c == 1 && bd.cblks_q == 2) bd.red_floats = 0;   // single owner wave: direct writes
   const int nc = 1 << g.nd;
   size_t off = 0;
   bd.off_wq = off;   off += align_up((size_t)g.K * bd.ochunks * bd.cblks_q * 2 * 64 * 16);

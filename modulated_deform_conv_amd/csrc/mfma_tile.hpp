@@ -81,6 +81,7 @@ struct BwdDims {
   int waves_c, cblks_q; // GEMM-1: waves along channels (4/2/1), 32-channel blocks of wq
   // workspace byte offsets
   int bias_tiles;       // pixel tiles of GEMM-1 = rows of the grad_bias partial sums
+  int red_floats;       // GEMM-1: floats of the grad_offset / grad_mask reduction buffer in LDS
   int sample_keyed;     // scatter lists: 1 = one entry per SAMPLE (3-D, mfma_csr3d.hip), 0 = per corner pair
   int S_e;              // list heads per (image, deformable group): anchor space (3-D) or S_i
   size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
