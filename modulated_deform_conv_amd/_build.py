@@ -37,10 +37,15 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+# mfma_bwd_data.hip: SLP vectorisation turns the drain's independent fp32 chains into v_pk_fma_f32 /
+# v_pk_add_f32 (10-24 cycles each on gfx950, tools/ubench_valu.hip) and blocks the DPP-operand fusion
+FILE_FLAGS = {"mfma_bwd_data.hip": ["-fno-slp-vectorize"]}
+
+
 def _compile(src):
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
     if _stale(obj, [src] + _deps()):
-        cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -56,7 +61,7 @@ def build_variant(name, extra_flags):
     objs = []
     for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
-        r = subprocess.run([_hipcc()] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj],
+        r = subprocess.run([_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + list(extra_flags) + ["-c", src, "-o", obj],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(r.stderr)

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   constexpr int BNP = 32 * WAVES_P;        // pixels per tile
   constexpr int RB = ND == 2 ? 8 : 4;      // accumulator rows per drain batch
   constexpr int NBATCH = MB * 16 / RB;
-  constexpr int SUB = 32 / NBATCH / 4;     // CL drain: quads of pixels per batch
+  constexpr int HS = NBATCH / 2, CPS = NC / HS;   // CL drain: batches per half tile, corners per batch
   constexpr int kOob = 0x7ffffff0;         // out-of-range buffer offset: loads give 0, stores drop
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int T_o = bd.ochunks;              // multiple of 4
@@ -163,15 +163,17 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   const rsrc_t r_gc = make_rsrc(gcol, (size_t)g.B * g.C * g.K * g.S_o * 4);
   const int a_lane = lane * 16;
   const float *Bb = Gs + (wp * 32 + (lane & 31)) * gpitch + 4 * kh;
-  // CL drain (line-wide gathers, see `gather`): per wave a parked-accumulator tile Pk[32][kPkPitch]
-  // ([pixel][channel]), and per pixel a state row St[kStRow]: 2^ND corner byte offsets into xt, the
-  // grad_col row offset, 2^ND reduced corner sums
-  constexpr int kPkPitch = 68, kStRow = 2 * NC + 4;
-  float *Pk = red + bd.red_floats + wave * (32 * kPkPitch);
-  int *St = reinterpret_cast<int *>(red + bd.red_floats + 4 * 32 * kPkPitch) + wave * (32 * kStRow);
-  const int gl_p = lane >> 4, gl_q = lane & 15;   // gather role: pixel of the quad-of-pixels, channel quad
+  // CL drain (line-wide gathers, see `gather`): per wave a parked-accumulator tile Pk[32][64]
+  // ([pixel][channel], 16-byte pieces XOR-swizzled by the pixel so that both the accumulator-layout
+  // writes and the gather-layout reads are bank-conflict free without padding), and per pixel a
+  // state row St[kStRow]: 2^ND corner byte offsets into xt, the grad_col row offset, 2^ND corner sums
+  constexpr int kStRow = 2 * NC + 4;
+  float *Pk = red + bd.red_floats + wave * (32 * 64);
+  int *St = reinterpret_cast<int *>(red + bd.red_floats + 4 * 32 * 64) + wave * (32 * kStRow);
+  const int gl_p = lane >> 2, gl_j = lane & 3;   // gather role: pixel of a half tile, lane of its quad
+  auto pk_swz = [](int p) { return ((p & 3) << 2) | ((p >> 2) & 3); };
   if (CL) {
-    for (int i = lane; i < 32 * kPkPitch; i += 64) Pk[i] = 0.f;
+    for (int i = lane; i < 32 * 64; i += 64) Pk[i] = 0.f;
     for (int i = lane; i < 32 * kStRow; i += 64) St[i] = kOob;
   }
 
@@ -394,23 +396,34 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   auto gather = [&](int q, int cbase_p, Batch &v) {
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
     if (CL) {
-      // Line-wide gathers: batch q covers the pixels [q * PPB, (q + 1) * PPB) of the wave's 32 for
-      // ALL 64 channels; lane = (pixel gl_p of a quad of pixels, channel quad gl_q), so the 16 lanes
-      // of a pixel read one 256-byte segment of xt per corner.  (With lane = pixel, the accumulator
-      // layout, every lane touched its own cache line: 55 L1 accesses per load instruction at cfg4,
-      // the texture path busy 97 % of the kernel -- profiles/r02_other_configs.md.)
-      const bool chan_ok = cbase_p + 4 * gl_q < g.C;
+      // Line-wide gathers: batch q covers one half of the wave's 32 pixels (16, all 64 channels) and
+      // CPS of their corners; a QUAD of lanes owns a pixel and reads a corner's 256-byte segment of
+      // xt as four 64-byte pieces (load k: bytes [64k + 16j, +16) for lane j), so every aligned
+      // quad of lanes reads 64 contiguous bytes -- the fast case of the texture path.  (With lane =
+      // pixel, the accumulator layout, every lane touched its own cache line: 55 L1 accesses per
+      // load instruction at cfg4, the texture path busy 97 % of the kernel.)
+      const int pxl = (q / HS) * 16 + gl_p;
+      const int *st = St + pxl * kStRow + (q % HS) * CPS;
+      const bool full = cbase_p + 64 <= g.C;
+      if (full) {   // (wave-uniform: the common case gets immediate offsets and no selects)
 #pragma unroll
-      for (int sp = 0; sp < SUB; ++sp) {
-        const int *st = St + ((q * SUB + sp) * 4 + gl_p) * kStRow;
-#pragma unroll
-        for (int c4 = 0; c4 < NC; c4 += 4) {
-          const int4 o = *reinterpret_cast<const int4 *>(st + c4);
-          const int ov[4] = {o.x, o.y, o.z, o.w};
+        for (int c = 0; c < CPS; ++c) {
+          const int o = st[c] + 16 * gl_j;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float4 x = buf_load4(r_in, chan_ok ? ov[k] + 16 * gl_q : kOob, cbase_p * 4);
-            float *d = v.f + ((sp * NC) + c4 + k) * 4;
+            const float4 x = buf_load4(r_in, o + 64 * k, cbase_p * 4);
+            float *d = v.f + (c * 4 + k) * 4;
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) {
+          const int o = st[c] + 16 * gl_j;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 x = buf_load4(r_in, cbase_p + 16 * k + 4 * gl_j < g.C ? o + 64 * k : kOob, cbase_p * 4);
+            float *d = v.f + (c * 4 + k) * 4;
             d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
           }
         }
@@ -432,34 +445,44 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   };
   auto consume = [&](int q, int cbase_p, const Batch &v) {
     if (CL) {
-      const bool chan_ok = cbase_p + 4 * gl_q < g.C;
+      const int pxl = (q / HS) * 16 + gl_p, cp = q % HS;
+      int *st = St + pxl * kStRow;
+      const int swz = pk_swz(pxl);
+      const bool full = cbase_p + 64 <= g.C;
+      float4 gc[4];
 #pragma unroll
-      for (int sp = 0; sp < SUB; ++sp) {
-        const int pxl = (q * SUB + sp) * 4 + gl_p;
-        int *st = St + pxl * kStRow;
-        const float4 gc = *reinterpret_cast<const float4 *>(Pk + pxl * kPkPitch + 4 * gl_q);
-        // grad_col row piece: the 16 lanes of a pixel store 256 contiguous bytes
-        buf_store4(r_gc, chan_ok ? st[NC] + 16 * gl_q : kOob, cbase_p * 4, gc.x, gc.y, gc.z, gc.w);
-        float s[NC];
+      for (int k = 0; k < 4; ++k)
+        gc[k] = *reinterpret_cast<const float4 *>(Pk + pxl * 64 + 4 * ((4 * k + gl_j) ^ swz));
+      if (cp == 0) {   // grad_col row: the quad stores 64 contiguous bytes per instruction
+        const int gv = st[NC] + 16 * gl_j;
 #pragma unroll
-        for (int ci = 0; ci < NC; ++ci) {
-          const float *x = v.f + (sp * NC + ci) * 4;
-          s[ci] = fmaf(gc.w, x[3], fmaf(gc.z, x[2], fmaf(gc.y, x[1], gc.x * x[0])));
-        }
-        // sum over the 16 lanes (64 channels) of the pixel: rotations inside the DPP row
-#pragma unroll
-        for (int ci = 0; ci < NC; ++ci) {
-          s[ci] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s[ci]), 0x128, 0xf, 0xf, false));
-          s[ci] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s[ci]), 0x124, 0xf, 0xf, false));
-          s[ci] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s[ci]), 0x122, 0xf, 0xf, false));
-          s[ci] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s[ci]), 0x121, 0xf, 0xf, false));
-        }
-        if (gl_q == 0) {
-#pragma unroll
-          for (int c4 = 0; c4 < NC; c4 += 4)
-            *reinterpret_cast<float4 *>(st + NC + 4 + c4) = make_float4(s[c4], s[c4 + 1], s[c4 + 2], s[c4 + 3]);
-        }
+        for (int k = 0; k < 4; ++k)
+          buf_store4(r_gc, (full || cbase_p + 16 * k + 4 * gl_j < g.C) ? gv + 64 * k : kOob, cbase_p * 4,
+                     gc[k].x, gc[k].y, gc[k].z, gc[k].w);
       }
+      float s[CPS];
+#pragma unroll
+      for (int c = 0; c < CPS; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float *x = v.f + (c * 4 + k) * 4;
+          a = fmaf(gc[k].w, x[3], fmaf(gc[k].z, x[2], fmaf(gc[k].y, x[1], fmaf(gc[k].x, x[0], a))));
+        }
+        s[c] = a;
+      }
+      // sum over the quad: DPP operands in asm (hipcc emits mov + mov_dpp + add for the builtin);
+      // the s_nops cover the VALU-write -> DPP-read hazard, which is not padded for inline asm
+      static_assert(CPS == 2, "two corners per step");
+      asm("s_nop 1\n\t"
+          "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1"
+          : "+v"(s[0]), "+v"(s[1]));
+      if (gl_j == 0) *reinterpret_cast<float2 *>(st + NC + 4 + cp * CPS) = make_float2(s[0], s[1]);
       return;
     }
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
@@ -501,12 +524,13 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   // park the accumulators of the finished K loop: registers (NCHW drain) or the LDS tile (CL)
   auto park = [&]() {
     if (CL) {
-      float *dst = Pk + (lane & 31) * kPkPitch + 4 * kh;
+      const int pix = lane & 31, swz = pk_swz(pix);
+      float *dst = Pk + pix * 64;
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq)
-          *reinterpret_cast<float4 *>(dst + i * 32 + 8 * rq) =
+          *reinterpret_cast<float4 *>(dst + 4 * ((i * 8 + 2 * rq + kh) ^ swz)) =
               make_float4(acc[i][4 * rq], acc[i][4 * rq + 1], acc[i][4 * rq + 2], acc[i][4 * rq + 3]);
     } else {
 #pragma unroll
@@ -1086,8 +1110,8 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
   const int bnp = 32 * (4 / bd.waves_c);
   const int passes = bd.cblks_q / (2 * bd.waves_c);
   const size_t red = (size_t)bd.red_floats;
-  // channels-last drain: parked accumulators [4 waves][32][68] + state rows [4 waves][32][2^nd * 2 + 4]
-  const size_t cl = bd.cl ? (size_t)4 * 32 * 68 + (size_t)4 * 32 * (2 * (1 << g.nd) + 4) : 0;
+  // channels-last drain: parked accumulators [4 waves][32][64] + state rows [4 waves][32][2^nd * 2 + 4]
+  const size_t cl = bd.cl ? (size_t)4 * 32 * 64 + (size_t)4 * 32 * (2 * (1 << g.nd) + 4) : 0;
   return ((size_t)bnp * (bd.ochunks * 16 + 4) + red + cl) * sizeof(float);
 }
 
