@@ -36,12 +36,18 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims
   constexpr int kPitch = CN + 1;
   __shared__ __attribute__((aligned(16))) float Bs[2 * BK * kPitch];
 
-  // blockIdx.x = (mtile * K + tap) * cblks + cblk ; blockIdx.y = split
-  int id = blockIdx.x;
+  // unit = split * (mtiles * K * cblks) + (mtile * K + tap) * cblks + cblk.  The linear block id
+  // is remapped so that every XCD (own L2) gets a contiguous run of units: the taps of one pixel
+  // split gather overlapping neighbourhoods of xt and read the same grad_out slabs, and now do so
+  // behind the same L2 (with tap-major dispatch order every tap streamed xt from HBM on its own:
+  // 8.7 GB of L2 misses per launch at cfg4, 6 TB/s -- the kernel was HBM-bound)
+  const int per_split = gridDim.x;
+  const int unit = xcd_remap(blockIdx.x + per_split * blockIdx.y, per_split * gridDim.y);
+  const int split = unit / per_split;
+  int id = unit - split * per_split;
   const int cblk = id % bd.cblks; id /= bd.cblks;
   const int tap = id % g.K;
   const int mtile = id / g.K;
-  const int split = blockIdx.y;
   const int c0 = cblk * CN;
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;

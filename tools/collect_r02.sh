@@ -24,6 +24,12 @@ bash tools/pmc_cfg.sh "FETCH_SIZE" cfg4 "" > $D/fetch_cfg4.txt 2>&1
 bash tools/pmc_cfg.sh "WRITE_SIZE" cfg4 "" > $D/write_cfg4.txt 2>&1
 bash tools/pmc_cfg.sh "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" cfg4 "" > $D/sq_cfg4.txt 2>&1
 bash tools/pmc_cfg.sh "GRBM_GUI_ACTIVE GRBM_TA_BUSY" cfg4 "" > $D/grbm_cfg4.txt 2>&1
+# cache path: L1 (TCP) accesses per vector-memory instruction, L2 (TCC) hit rate
+for c in cfg3 cfg4 cfg5; do
+  bash tools/pmc_cfg.sh "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" $c "" > $D/tcp_$c.txt 2>&1
+  bash tools/pmc_cfg.sh "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" $c "" > $D/tcc_$c.txt 2>&1
+  bash tools/pmc_cfg.sh "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU" $c "" > $D/vmem_$c.txt 2>&1
+done
 (cd /tmp && timeout 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D -o fetchcal -- $ROOT/tools/ubench_fetch > $D/fetchcal.log 2>&1)
 ./tools/ubench_gather16 > $D/ubench_gather16.txt 2>&1
 tail -3 $D/configs.txt
