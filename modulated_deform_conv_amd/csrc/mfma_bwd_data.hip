@@ -802,19 +802,30 @@ __global__ __launch_bounds__(256) void zero_int_kernel(int *__restrict__ p, int6
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
 }
 
-// exclusive scan of cnt[seg][0..S_i) -> rowptr[seg][0..S_i], one workgroup per segment
-__global__ __launch_bounds__(256) void csr_scan_kernel(int S_i, const int *__restrict__ cnt,
-                                                       int *__restrict__ rowptr) {
+// exclusive scan of cnt[seg][0..S) -> rowptr[seg][0..S]: grid (chunks of kScanChunk elements,
+// segments).  A workgroup first sums everything before its chunk (the counters are L2-resident and
+// that is at most S reads), then scans its chunk -- one workgroup per SEGMENT, as in round 1, left
+// 8 workgroups walking 35 k anchors each at the 3-D shards (0.12 / 0.22 ms at cfg4 / cfg5).
+constexpr int kScanChunk = 2048;
+__global__ __launch_bounds__(256) void csr_scan_kernel(int S, const int *__restrict__ cnt,
+                                            int *__restrict__ rowptr) {
   __shared__ int wsum[4];
   __shared__ int carry;
-  const int seg = blockIdx.x;
-  const int *c = cnt + (int64_t)seg * S_i;
-  int *rp = rowptr + (int64_t)seg * (S_i + 1);
-  if (threadIdx.x == 0) carry = 0;
+  const int seg = blockIdx.y;
+  const int lo = blockIdx.x * kScanChunk, hi = min(lo + kScanChunk, S);
+  const int *c = cnt + (int64_t)seg * S;
+  int *rp = rowptr + (int64_t)seg * (S + 1);
+  int pre = 0;
+  for (int i = threadIdx.x; i < lo; i += 256) pre += c[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = pre;
   __syncthreads();
-  for (int base = 0; base < S_i; base += 256) {
+  if (threadIdx.x == 0) carry = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  for (int base = lo; base < hi; base += 256) {
     const int i = base + threadIdx.x;
-    const int v = i < S_i ? c[i] : 0;
+    const int v = i < hi ? c[i] : 0;
     int x = v;   // inclusive scan inside the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -826,12 +837,12 @@ __global__ __launch_bounds__(256) void csr_scan_kernel(int S_i, const int *__res
     int woff = 0;
     for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) woff += wsum[k];
     const int excl = carry + woff + x - v;
-    if (i < S_i) rp[i] = excl;
+    if (i < hi) rp[i] = excl;
     __syncthreads();
     if (threadIdx.x == 255) carry = excl + v;
     __syncthreads();
   }
-  if (threadIdx.x == 0) rp[S_i] = carry;
+  if (hi == S && threadIdx.x == 0) rp[S] = carry;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1181,7 +1192,8 @@ int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, 
   const int64_t samples = (int64_t)g.B * g.DG * g.K * g.S_o;
   const int64_t cnt_n = (int64_t)g.B * g.DG * bd.S_e;
   int rc;
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(g.B * g.DG), dim3(256), 0, stream, bd.S_e, cnt, rowptr);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3((bd.S_e + kScanChunk - 1) / kScanChunk, g.B * g.DG), dim3(256), 0,
+                     stream, bd.S_e, cnt, rowptr);
   if ((rc = check_launch("csr_scan"))) return rc;
   hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
   if ((rc = check_launch("zero_cnt"))) return rc;
