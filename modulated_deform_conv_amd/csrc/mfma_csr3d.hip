@@ -10,7 +10,7 @@
 // rows (z-1 | z, y-1 | y) at columns x-1 and x; the walk along x keeps the `cur` / `nxt`
 // accumulators of the 2-D scheme, so a grad_col row is still read once per anchor row it feeds.
 // Measured at cfg4 against the pair-keyed lists: 4x fewer counting atomics inside GEMM-1, 4x fewer
-// cursor atomics and entries in the fill pass (1.21 ms -> see profiles/), the gather about equal.
+// cursor atomics and entries in the fill pass (1.21 -> 0.22 ms).
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
 
@@ -18,7 +18,7 @@ namespace mdconv {
 
 namespace {
 
-constexpr int kRun3 = 8;                 // targets per run
+constexpr int kRun3 = 4;                 // consecutive x targets of a run (x 2 x 2 in y, z)
 constexpr int kOob3 = 0x7ffffff0;        // out-of-range buffer offset: loads give 0
 
 int grid_for3(int64_t total) {
@@ -61,32 +61,40 @@ __global__ __launch_bounds__(256) void csr_fill3d_kernel(Geom g, int S_e, const 
   }
 }
 
-// LPD lanes (4 channels each) follow one list; a wave walks 64 / LPD runs of kRun3 consecutive
-// targets side by side; workgroup tile = 4 * (64 / LPD) runs.  Channel units of LPD * 4 channels
-// (inside one deformable group) are processed one after the other.
+// LPD lanes (4 channels each) follow one list.  A RUN owns a 2 x 2 x kRun3 block of targets
+// (z0 | z0+1, y0 | y0+1, kRun3 consecutive x) and walks the 3 x 3 anchor rows that reach it along
+// x with the `cur` / `nxt` carry, so a grad_col row (and its list entry) is read ONCE for all the
+// targets of the block it feeds: 9 anchor-row visits per 4 target rows instead of 16 (a single
+// target row per run re-read every row 4x from HBM: L2 hit 27 %, 6.2 GB at cfg4).  A wave walks
+// 64 / LPD runs side by side; workgroup tile = 4 * (64 / LPD) runs; channel units of LPD * 4
+// channels (inside one deformable group) are processed one after the other.
+// (cfg4: 0.91 -> 0.78 ms.  The same walk on the 16-bit rows of the cfg5 shard -- 203 registers with
+// 8 channels per lane -- measured 7 % SLOWER than one target row per run and is not used there.)
 template <int LPD>
 __global__ __launch_bounds__(256) void col2im3d_kernel(Geom g, int S_e, const float *__restrict__ gcol,
                                                        const int *__restrict__ rowptr,
                                                        const int4 *__restrict__ entries,
                                                        float *__restrict__ grad_input) {
-  constexpr int NR = 4;                    // anchor rows that reach a target
-  constexpr int NQ = 64 / LPD, RUNS = 4 * NQ, QT = RUNS * kRun3;
+  constexpr int NQ = 64 / LPD, RUNS = 4 * NQ, RT = 4 * kRun3, QT = RUNS * RT;   // targets per run / tile
   constexpr int CW = LPD * 4;              // channels per unit
   constexpr int UB = LPD < 8 ? LPD : 8;    // row loads in flight per step
   constexpr int TP = QT + 1;               // LDS pitch
-  __shared__ float tile[CW * TP];
-  const int qtiles = (g.S_i + QT - 1) / QT;
+  __shared__ float tile[CW * TP];          // [channel][target row t][run][x]
+  const int D = g.in_sz[0], H = g.in_sz[1], W = g.in_sz[2];
+  const int nrx = (W + kRun3 - 1) / kRun3, nry = (H + 1) / 2, nrz = (D + 1) / 2;
+  const int runs_img = nrx * nry * nrz, tiles_img = (runs_img + RUNS - 1) / RUNS;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = bid / qtiles;
-  const int q0 = (bid - b * qtiles) * QT;
+  const int b = bid / tiles_img;
+  const int r0 = (bid - b * tiles_img) * RUNS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane / LPD, r = lane % LPD;
   const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * g.C, (size_t)g.K * g.S_o * g.C * 4);
   const int cseg = g.DG == 1 ? g.C : g.Cdg;     // channels that share one list
   const int upd = (cseg + CW - 1) / CW;         // units per segment
   const int units = g.DG * upd;
-  const int qs = q0 + (wave * NQ + j) * kRun3;
-  const int W = g.in_sz[2];
+  const int run = wave * NQ + j, rg = r0 + run;
+  const bool run_on = rg < runs_img;
+  const int xs = (rg % nrx) * kRun3, y0 = ((rg / nrx) % nry) * 2, z0 = (rg / (nrx * nry)) * 2;
   for (int u = 0; u < units; ++u) {
     const int dg = u / upd;
     const int c_lo = dg * cseg + (u - dg * upd) * CW;          // first channel of the unit
@@ -97,78 +105,102 @@ __global__ __launch_bounds__(256) void col2im3d_kernel(Geom g, int S_e, const fl
     const int *rp = rowptr + (int64_t)seg * (S_e + 1);
     const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * 2;
     const int c_voff = chan_on ? c4 * 4 : kOob3;
-    // coordinates of the target of the current step (first step: qs - 1, the carry-in column)
-    int tc[3];
-    {
-      int rem = max(qs - 1, 0);
-      tc[2] = rem % g.in_sz[2]; rem /= g.in_sz[2];
-      tc[1] = rem % g.in_sz[1];
-      tc[0] = rem / g.in_sz[1];
-      if (qs - 1 < 0) tc[2] = -1;
-    }
-    float4 cur = make_float4(0.f, 0.f, 0.f, 0.f), nxt = cur;
+    float4 cur[4], nxt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cur[t] = nxt[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int step = 0; step <= kRun3; ++step) {
-      const int a = qs - 1 + step;
-      const bool on = a >= 0 && a < g.S_i;
+      const int xa = xs - 1 + step;          // anchor column: feeds targets xa (cur) and xa + 1 (nxt)
+      const bool on = run_on && xa >= 0 && xa < W;
+      // list bounds of the 9 anchor rows first (independent loads, one latency instead of nine).
+      // Anchor row (extended low index) e = (z0 + dz, y0 + dy): on an axis it feeds target e - 1
+      // with the sample's low weight and target e with its high weight
+      int e0s[9], e1s[9];
 #pragma unroll
-      for (int s = 0; s < NR; ++s) {
-        // anchor row s: extended low index = target + s_a on the two outer axes
-        const int er = (tc[0] + ((s >> 1) & 1)) * (g.in_sz[1] + 1) + tc[1] + (s & 1);
-        const int ea = er * W + tc[2];
-        const int e0 = on ? rp[ea] : 0, e1 = on ? rp[ea + 1] : 0;
-        for (int base = e0; __any(base < e1); base += LPD) {
-          const int cnt = max(0, min(LPD, e1 - base));
-          int src_m = 0;
-          float fx_m = 0.f, fy_m = 0.f;   // weights 0, row 0 beyond the list
-          if (r < cnt) {
-            const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
-            // target = low + 1 - s_a on axis a: s_a = 1 -> the low side, 0 -> the high side
-            const float rw = (((s >> 1) & 1) ? __int_as_float(ea4.w) : __int_as_float(eb4.x)) *
-                             ((s & 1) ? __int_as_float(eb4.y) : __int_as_float(eb4.z));
-            src_m = ea4.x;
-            fx_m = rw * __int_as_float(ea4.y);
-            fy_m = rw * __int_as_float(ea4.z);
-          }
+      for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-          for (int u0 = 0; u0 < LPD; u0 += UB) {
-            float4 v[UB];
-            float wx[UB], wy[UB];
+        for (int dy = 0; dy < 3; ++dy) {
+          const int ez = z0 + dz, ey = y0 + dy;
+          const bool row_on = on && ez <= D && ey <= H;
+          const int ea = (ez * (H + 1) + ey) * W + xa;
+          e0s[dz * 3 + dy] = row_on ? rp[ea] : 0;
+          e1s[dz * 3 + dy] = row_on ? rp[ea + 1] : 0;
+        }
 #pragma unroll
-            for (int k = 0; k < UB; ++k) {
-              const int src = __shfl(src_m, u0 + k, LPD);
-              wx[k] = __shfl(fx_m, u0 + k, LPD);
-              wy[k] = __shfl(fy_m, u0 + k, LPD);
-              v[k] = buf_load4(r_gc, src * g.C * 4 + c_voff, 0);
+      for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int e0 = e0s[dz * 3 + dy], e1 = e1s[dz * 3 + dy];
+          for (int base = e0; __any(base < e1); base += LPD) {
+            const int cnt = max(0, min(LPD, e1 - base));
+            int src_m = 0;
+            float px_m[4], py_m[4];   // per target of the block: weight on column xa / xa + 1
+#pragma unroll
+            for (int t = 0; t < 4; ++t) px_m[t] = py_m[t] = 0.f;
+            if (r < cnt) {
+              const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
+              src_m = ea4.x;
+              const float fx = __int_as_float(ea4.y), fy = __int_as_float(ea4.z);
+              const float zl = __int_as_float(ea4.w), zh = __int_as_float(eb4.x);
+              const float yl = __int_as_float(eb4.y), yh = __int_as_float(eb4.z);
+#pragma unroll
+              for (int iz = 0; iz < 2; ++iz)
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy) {
+                  if ((iz == dz - 1 || iz == dz) && (iy == dy - 1 || iy == dy)) {
+                    const float w = (iz == dz ? zh : zl) * (iy == dy ? yh : yl);
+                    px_m[iz * 2 + iy] = w * fx;
+                    py_m[iz * 2 + iy] = w * fy;
+                  }
+                }
             }
 #pragma unroll
-            for (int k = 0; k < UB; ++k) {
-              cur.x = fmaf(wx[k], v[k].x, cur.x); cur.y = fmaf(wx[k], v[k].y, cur.y);
-              cur.z = fmaf(wx[k], v[k].z, cur.z); cur.w = fmaf(wx[k], v[k].w, cur.w);
-              nxt.x = fmaf(wy[k], v[k].x, nxt.x); nxt.y = fmaf(wy[k], v[k].y, nxt.y);
-              nxt.z = fmaf(wy[k], v[k].z, nxt.z); nxt.w = fmaf(wy[k], v[k].w, nxt.w);
+            for (int u0 = 0; u0 < LPD; u0 += UB) {
+              float4 v[UB];
+#pragma unroll
+              for (int k = 0; k < UB; ++k) {
+                const int src = __shfl(src_m, u0 + k, LPD);
+                v[k] = buf_load4(r_gc, src * g.C * 4 + c_voff, 0);
+              }
+#pragma unroll
+              for (int k = 0; k < UB; ++k) {
+#pragma unroll
+                for (int iz = 0; iz < 2; ++iz)
+#pragma unroll
+                  for (int iy = 0; iy < 2; ++iy) {
+                    if ((iz == dz - 1 || iz == dz) && (iy == dy - 1 || iy == dy)) {
+                      const int t = iz * 2 + iy;
+                      const float wx = __shfl(px_m[t], u0 + k, LPD), wy = __shfl(py_m[t], u0 + k, LPD);
+                      cur[t].x = fmaf(wx, v[k].x, cur[t].x); cur[t].y = fmaf(wx, v[k].y, cur[t].y);
+                      cur[t].z = fmaf(wx, v[k].z, cur[t].z); cur[t].w = fmaf(wx, v[k].w, cur[t].w);
+                      nxt[t].x = fmaf(wy, v[k].x, nxt[t].x); nxt[t].y = fmaf(wy, v[k].y, nxt[t].y);
+                      nxt[t].z = fmaf(wy, v[k].z, nxt[t].z); nxt[t].w = fmaf(wy, v[k].w, nxt[t].w);
+                    }
+                  }
+              }
             }
           }
         }
       }
       if (step > 0 && chan_on) {
-        float *tp = tile + (r * 4) * TP + (a - q0);
-        tp[0] = cur.x; tp[TP] = cur.y; tp[2 * TP] = cur.z; tp[3 * TP] = cur.w;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float *tp = tile + (r * 4) * TP + t * (RUNS * kRun3) + run * kRun3 + step - 1;
+          tp[0] = cur[t].x; tp[TP] = cur[t].y; tp[2 * TP] = cur[t].z; tp[3 * TP] = cur[t].w;
+        }
       }
-      cur = nxt;
-      nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-      // next target along the flattened image
-      if (++tc[2] == W) {
-        tc[2] = 0;
-        if (++tc[1] == g.in_sz[1]) { tc[1] = 0; ++tc[0]; }
-      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { cur[t] = nxt[t]; nxt[t] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
     __syncthreads();
-    // transpose out: consecutive threads -> consecutive q of one channel
+    // transpose out: consecutive threads -> consecutive x of one (channel, target row)
     for (int x = threadIdx.x; x < CW * QT; x += 256) {
       const int cl = x / QT, ql = x - cl * QT;
-      const int c = c_lo + cl, q = q0 + ql;
-      if (c < c_end && q < g.S_i) {
-        float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q;
+      const int t = ql / (RUNS * kRun3), wr = (ql / kRun3) % RUNS, wk = ql % kRun3;
+      const int wg = r0 + wr;
+      const int wx = (wg % nrx) * kRun3 + wk, wy = ((wg / nrx) % nry) * 2 + (t & 1), wz = (wg / (nrx * nry)) * 2 + (t >> 1);
+      const int c = c_lo + cl;
+      if (c < c_end && wg < runs_img && wz < D && wy < H && wx < W) {
+        float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + (wz * H + wy) * W + wx;
         const float v = tile[cl * TP + ql];
         *dst = g.acc_data ? *dst + v : v;
       }
@@ -197,8 +229,9 @@ int col2im3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float
   const int lanes = (cseg + 3) / 4;
 #define C2I3(LPD)                                                                                \
   do {                                                                                           \
-    const int qt = 4 * (64 / LPD) * kRun3;                                                       \
-    hipLaunchKernelGGL((col2im3d_kernel<LPD>), dim3(g.B * ((g.S_i + qt - 1) / qt)), dim3(256), 0, \
+    const int runs = 4 * (64 / LPD);                                                             \
+    const int runs_img = ((g.in_sz[2] + kRun3 - 1) / kRun3) * ((g.in_sz[1] + 1) / 2) * ((g.in_sz[0] + 1) / 2); \
+    hipLaunchKernelGGL((col2im3d_kernel<LPD>), dim3(g.B * ((runs_img + runs - 1) / runs)), dim3(256), 0, \
                        stream, g, bd.S_e, gcol, rowptr, (const int4 *)entries,                   \
                        (float *)t.grad_input);                                                   \
   } while (0)
