@@ -100,7 +100,6 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
 //
 // QPQ > 0: the K loop has exactly QPQ * NBATCH quads (4 chunks each) and is emitted as
 // straight-line code; QPQ == 0: any shape, runtime loops.
-constexpr int kTapGroup = 9;
 
 // CL: the drain gathers from the channels-last input copy xt[b][q][c] (mfma_fwd_cl.hip): a lane
 // fetches 4 consecutive channels of ONE corner of its pixel with a 16-byte load -- half the load
@@ -124,7 +123,8 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   const int T_o = bd.ochunks;              // multiple of 4
   const int gpitch = T_o * 16 + 4;         // floats per pixel row of the grad_out tile
   float *Gs = smem;                        // [BNP][gpitch]
-  float *red = smem + BNP * gpitch;        // [kTapGroup][nblk][ND + 1][BNP]
+  float *red = smem + BNP * gpitch;        // [bd.tap_group][nblk][ND + 1][BNP]
+  const int kTapGroup = bd.tap_group;      // taps whose grad_offset / grad_mask partials are flushed together
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
   // wave id as an SGPR: anything derived from threadIdx is 'divergent' to hipcc, and a divergent
@@ -1122,7 +1122,7 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
   const int passes = bd.cblks_q / (2 * bd.waves_c);
   const size_t red = (size_t)bd.red_floats;
   // channels-last drain: parked accumulators [4 waves][32][64] + state rows [4 waves][32][2^nd * 2 + 4]
-  const size_t cl = bd.cl ? (size_t)4 * 32 * 64 + (size_t)4 * 32 * (2 * (1 << g.nd) + 4) : 0;
+  const size_t cl = bd.cl_drain ? (size_t)4 * 32 * 64 + (size_t)4 * 32 * (2 * (1 << g.nd) + 4) : 0;
   return ((size_t)bnp * (bd.ochunks * 16 + 4) + red + cl) * sizeof(float);
 }
 
@@ -1157,7 +1157,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
 /* channels-last drain only where it pays (3-D) */                                                \
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
   do {                                                                                          \
-    if (xt != nullptr && (ND == 3 || QPQ == 0)) LAUNCH_BD_(ND, MOD, WC, QPQ, (ND == 3 || QPQ == 0)); \
+    if (xt != nullptr && bd.cl_drain) LAUNCH_BD_(ND, MOD, WC, QPQ, true);                       \
     else LAUNCH_BD_(ND, MOD, WC, QPQ, false);                                                   \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \

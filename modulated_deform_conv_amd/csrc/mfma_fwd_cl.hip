@@ -284,9 +284,12 @@ bool bwd_channels_last(const Geom &g) {
   if (g.C % kSlab || (g.DG != 1 && g.Cdg % kSlab)) return false;   // a 64-channel block = one group
   static const int env = getenv("MDCONV_BWD_CL") ? atoi(getenv("MDCONV_BWD_CL")) : -1;   // read once
   if (env >= 0) return env != 0;
-  // 3-D always; 2-D only where GEMM-1 is bound by its drain rather than by the matrix work: many
-  // conv groups leave one quad of K per tap (cfg3 shape: backward 2.58 -> 2.39 ms; cfg2: no gain)
-  return g.nd == 3 || g.G >= 8;
+  // 3-D always.  2-D: the NCHW pair gathers cost ~30 L1 accesses per 512-byte load instruction at
+  // cfg2 (random offsets put every lane in its own sector; the three GEMMs keep the L1 70-75 %
+  // busy), the channels-last ones 16 per KiB -- with the line-wide drain of GEMM-1 and the XCD-aware
+  // unit order of GEMM-2 the backward is 4-25 % faster over the 2-D shapes of tools/cl_sweep.py
+  // (cfg2 2.85 -> 2.75 ms) once the layout pass is amortised: from ~16 k output pixels up.
+  return g.nd == 3 || g.G >= 8 || g.N >= 16384;
 }
 
 int nchw_to_nhwc_f32(const Geom &g, const float *x, float *xt, hipStream_t stream) {

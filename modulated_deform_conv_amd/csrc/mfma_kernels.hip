@@ -123,9 +123,33 @@ BwdDims bwd_dims(const Geom &g) {
   bd.ochunks = (g.O + 63) / 64 * 4;   // K loop of GEMM-1 is unrolled 4x
   bd.waves_c = g.C > 128 ? 4 : (g.C > 64 ? 2 : 1);
   bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
-  // [tap group of 9][64-channel blocks to reduce][nd + 1][pixels of the tile], see mfma_bwd_data.hip
-  bd.red_floats = 9 * 128 * (g.DG > 1 ? bd.cblks_q / (2 * bd.waves_c) : 1) * (g.nd + 1);
-  if (g.DG == 1 && bd.waves_c == 1 && bd.cblks_q == 2) bd.red_floats = 0;   // single owner wave: direct writes
+  // GEMM-1 drain: channels-last (line-wide gathers through an LDS hand-over, mfma_bwd_data.hip)
+  // whenever the backward has the channels-last copy -- except for straight-line 2-D shapes whose
+  // LDS (grad_out tile + parked accumulators) would then allow only one workgroup per CU
+  // (C_in = 128, C_out = 256: 1.56 -> 1.70 ms).  MDCONV_BD_CL = 0 / 1 overrides.
+  // Reduction buffer [tap group][64-channel blocks to reduce][nd + 1][pixels of the tile]: groups of
+  // 3 taps instead of 9 where that keeps the kernel under 80 KB of LDS (two workgroups per CU).
+  const int red_per_tap = 128 * (g.DG > 1 ? bd.cblks_q / (2 * bd.waves_c) : 1) * (g.nd + 1);
+  const bool single_owner = g.DG == 1 && bd.waves_c == 1 && bd.cblks_q == 2;   // direct writes, no buffer
+  auto size_red = [&]() {
+    bd.tap_group = 9;
+    bd.red_floats = single_owner ? 0 : bd.tap_group * red_per_tap;
+    if (bd.red_floats && bwd_data_lds_bytes(g, bd) > 80 * 1024) {
+      bd.tap_group = 3;
+      bd.red_floats = bd.tap_group * red_per_tap;
+    }
+  };
+  {
+    const int nbatch = g.nd == 2 ? 4 : 8, nquads = bd.ochunks / 4;
+    const bool straight = g.nd == 2 && g.G == 1 && nquads % nbatch == 0 && nquads / nbatch <= 2;
+    static const int bd_cl_env = getenv("MDCONV_BD_CL") ? atoi(getenv("MDCONV_BD_CL")) : -1;
+    bd.cl_drain = bd.cl;
+    size_red();
+    if (bd.cl && straight && (bd_cl_env == 0 || (bd_cl_env < 0 && bwd_data_lds_bytes(g, bd) > 80 * 1024))) {
+      bd.cl_drain = 0;
+      size_red();
+    }
+  }
   const int nc = 1 << g.nd;
   size_t off = 0;
   bd.off_wq = off;   off += align_up((size_t)g.K * bd.ochunks * bd.cblks_q * 2 * 64 * 16);

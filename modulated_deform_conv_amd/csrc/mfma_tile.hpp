@@ -82,6 +82,8 @@ struct BwdDims {
   // workspace byte offsets
   int bias_tiles;       // pixel tiles of GEMM-1 = rows of the grad_bias partial sums
   int red_floats;       // GEMM-1: floats of the grad_offset / grad_mask reduction buffer in LDS
+  int tap_group;        // GEMM-1: taps per flush of that buffer (9; 3 where LDS is short)
+  int cl_drain;         // GEMM-1 drains through the channels-last copy (line-wide gathers)
   int sample_keyed;     // scatter lists: 1 = one entry per SAMPLE (3-D, mfma_csr3d.hip), 0 = per corner pair
   int S_e;              // list heads per (image, deformable group): anchor space (3-D) or S_i
   size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
