@@ -364,6 +364,15 @@ __global__ __launch_bounds__(kThreads) void direct_bwd_weight_kernel(
   }
 }
 
+// dynamic LDS above the 64 KB default needs an explicit opt-in per kernel (gfx950: 160 KB per workgroup)
+constexpr size_t kMaxLds = 160 * 1024;
+template <typename K> int allow_lds(K kernel, size_t smem) {
+  if (smem <= 64 * 1024) return MDCONV_OK;
+  hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MDCONV_ELAUNCH; }
+  return MDCONV_OK;
+}
+
 int pick_cc(const Geom &g, int TO, size_t elem) {
   const int budget = 32 * 1024;
   int cc = (int)(budget / ((size_t)g.K * TO * elem));
@@ -378,14 +387,18 @@ int launch_fwd(const Geom &g, const Tensors &t, hipStream_t stream) {
   constexpr int TO = 16;
   const int cc = pick_cc(g, TO, sizeof(A));
   const size_t smem = (size_t)cc * g.K * TO * sizeof(A);
-  if (smem > 64 * 1024) {
-    set_error("direct_fwd: kernel volume K=%d too large for the LDS weight tile", g.K);
+  const int otiles = (g.Og + TO - 1) / TO;
+  if (smem > kMaxLds || (int64_t)g.G * otiles > 65535) {
+    set_error("direct_fwd: kernel volume K=%d / group count beyond the LDS weight tile or the grid", g.K);
     return MDCONV_EUNSUPPORTED;
   }
-  const int otiles = (g.Og + TO - 1) / TO;
   dim3 grid((g.N + kThreads - 1) / kThreads, g.G * otiles);
+  int rc_lds;
   const bool pair = g.in_sz[g.nd - 1] >= 2 &&
                     (size_t)g.B * g.C * g.S_i * sizeof(T) < 0xfffffff0ull;
+  if ((rc_lds = pair ? allow_lds(direct_fwd_kernel<T, ND, MOD, TO, true>, smem)
+                     : allow_lds(direct_fwd_kernel<T, ND, MOD, TO, false>, smem)))
+    return rc_lds;
   if (pair)
     hipLaunchKernelGGL((direct_fwd_kernel<T, ND, MOD, TO, true>), grid, dim3(kThreads), smem, stream, g,
                        cc, (const T *)t.input, (const T *)t.weight, (const T *)t.bias,
@@ -404,11 +417,13 @@ int launch_bwd(const Geom &g, const Tensors &t, hipStream_t stream, int parts) {
     constexpr int TO = 32;
     const int cc = pick_cc(g, TO, sizeof(A));
     const size_t smem = (size_t)cc * g.K * TO * sizeof(A);
-    if (smem > 64 * 1024) {
-      set_error("direct_bwd_data: kernel volume K=%d too large for the LDS weight tile", g.K);
+    const int otiles = (g.Og + TO - 1) / TO;
+    if (smem > kMaxLds || (int64_t)g.G * otiles > 65535) {
+      set_error("direct_bwd_data: kernel volume K=%d / group count beyond the LDS weight tile or the grid", g.K);
       return MDCONV_EUNSUPPORTED;
     }
-    const int otiles = (g.Og + TO - 1) / TO;
+    int rc_lds = allow_lds(direct_bwd_data_kernel<T, ND, MOD, TO>, smem);
+    if (rc_lds) return rc_lds;
     dim3 grid((g.N + kThreads - 1) / kThreads, g.G * otiles);
     hipLaunchKernelGGL((direct_bwd_data_kernel<T, ND, MOD, TO>), grid, dim3(kThreads), smem, stream,
                        g, cc, (const T *)t.input, (const T *)t.weight, (const T *)t.offset,

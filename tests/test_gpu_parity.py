@@ -61,6 +61,14 @@ def test_fp64(case):
     _check(case, torch.float64, "auto")
 
 
+def test_large_kernel_volume_uses_the_big_lds_tile():
+    """7x7x7 taps (K = 343): the direct path's fp64 backward weight tile is 88 KB, above the 64 KB
+    default of dynamic LDS (the reference handles any kernel volume; gfx950 allows 160 KB)."""
+    from tests.cases import D3, M3, _c
+    _check(_c("dcn3d_k7", D3, 1, 2, 2, (6, 6, 6), 7, padding=3, seed=61), torch.float64, "auto")
+    _check(_c("mdcn3d_k7", M3, 1, 2, 4, (5, 6, 5), 7, padding=3, seed=62), torch.float32, "auto")
+
+
 @pytest.mark.parametrize("case", [c for c in CASES if c["tier"] == "small"][::2] +
                          [c for c in CASES if c["tier"] == "medium"][:2], ids=lambda c: c["name"])
 def test_fp16(case):
