@@ -39,28 +39,40 @@ __device__ unsigned long long g_hp_timing[16];
 #define HP_T(slot) do { } while (0)
 #endif
 
-// S[i] += S[i] of the partner lane, for NC values at once: level 0 / 1 = quad_perm swaps (lane ^ 1,
-// lane ^ 2), level 2 = row_half_mirror (lane i <-> 7 - i of its 8), level 3 = row_mirror (i <-> 15 - i).
-// Inline asm because hipcc lowers the DPP builtin to mov + mov_dpp + add; the leading s_nop covers
-// the VALU-write -> DPP-read hazard (2 wait states), which is not padded for inline asm.
-#define HP_DPP4(MOD)                                                                              \
-  asm("s_nop 1\n\t"                                                                               \
+// Sum of S[i] over the `sub` (a power of two, wave-uniform) lanes of a group, up to 16 lanes = one DPP
+// row: quad_perm swaps (lane ^ 1, lane ^ 2), then row_half_mirror (lane i <-> 7 - i of its 8) and
+// row_mirror (i <-> 15 - i), which pair lanes that already hold equal quad / half-row sums.
+// ONE asm statement with scalar branches on `sub` inside: hipcc lowers the DPP builtin to mov +
+// mov_dpp + add, and separate conditional statements cost a register copy per value and level;
+// the s_nops cover the VALU-write -> DPP-read hazard (2 wait states), not padded for inline asm.
+#define HP_DPP_LVL(MOD)                                                                           \
       "v_add_f32_dpp %0, %0, %0 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
       "v_add_f32_dpp %1, %1, %1 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
       "v_add_f32_dpp %2, %2, %2 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
       "v_add_f32_dpp %3, %3, %3 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
-      "s_nop 1"                                                                                   \
-      : "+v"(S[o]), "+v"(S[o + 1]), "+v"(S[o + 2]), "+v"(S[o + 3]))
-template <int NC> __device__ __forceinline__ void hp_dpp_add(float (&S)[NC], int level) {
+      "s_nop 1\n\t"
+template <int NC> __device__ __forceinline__ void hp_dpp_sum(float (&S)[NC], int sub) {
 #pragma unroll
-  for (int o = 0; o < NC; o += 4) {
-    if (level == 0) HP_DPP4("quad_perm:[1,0,3,2]");
-    else if (level == 1) HP_DPP4("quad_perm:[2,3,0,1]");
-    else if (level == 2) HP_DPP4("row_half_mirror");
-    else HP_DPP4("row_mirror");
-  }
+  for (int o = 0; o < NC; o += 4)
+    asm("s_nop 1\n\t"
+        "s_cmp_lt_i32 %4, 2\n\t"
+        "s_cbranch_scc1 Ldpp_end%=\n\t"
+        HP_DPP_LVL("quad_perm:[1,0,3,2]")
+        "s_cmp_lt_i32 %4, 4\n\t"
+        "s_cbranch_scc1 Ldpp_end%=\n\t"
+        HP_DPP_LVL("quad_perm:[2,3,0,1]")
+        "s_cmp_lt_i32 %4, 8\n\t"
+        "s_cbranch_scc1 Ldpp_end%=\n\t"
+        HP_DPP_LVL("row_half_mirror")
+        "s_cmp_lt_i32 %4, 16\n\t"
+        "s_cbranch_scc1 Ldpp_end%=\n\t"
+        HP_DPP_LVL("row_mirror")
+        "Ldpp_end%=:"
+        : "+v"(S[o]), "+v"(S[o + 1]), "+v"(S[o + 2]), "+v"(S[o + 3])
+        : "s"(sub)
+        : "scc");
 }
-#undef HP_DPP4
+#undef HP_DPP_LVL
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // 8 consecutive K values of this lane's matrix column from a row-major [K][N] LDS tile: two
@@ -438,12 +450,8 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
           }
           *reinterpret_cast<U4 *>(Col + it_p[k] * pitch_gc + it_oc[k] * 8) = pack8<T>(col);
           // reduce S over the `sub` lanes that share (pixel, dg); partials -> LDS.  Up to 16 lanes
-          // (one DPP row) with DPP operands -- quad swaps, then the half-row and row mirrors, which
-          // pair lanes that already hold equal quad / half-row sums; ds_bpermute only beyond
-          if (sub >= 2) hp_dpp_add<NC>(S, 0);
-          if (sub >= 4) hp_dpp_add<NC>(S, 1);
-          if (sub >= 8) hp_dpp_add<NC>(S, 2);
-          if (sub >= 16) hp_dpp_add<NC>(S, 3);
+          // (one DPP row) with DPP operands, ds_bpermute only beyond
+          hp_dpp_sum<NC>(S, sub);
           for (int d = 16; d < sub; d <<= 1)
 #pragma unroll
             for (int ci = 0; ci < NC; ++ci) S[ci] += __shfl_xor(S[ci], d, 64);
