@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
             ev[ci] = (f.live && hc.idx[ci] >= 0) ? (bb * g.S_i + hc.idx[ci]) * Cp * 2 : kHpOob;
             ev[NC + ci] = __float_as_int(f.live ? hc.w[ci] * ml[ps] : 0.f);
           }
-          ev[2 * NC] = f.live ? (bb * g.K + tap) * g.S_o + pix : -1;   // grad_col row index
+          ev[2 * NC] = f.live ? ((bb * g.K + tap) * g.S_o + pix) * Cp * 2 : kHpOob;   // grad_col row, byte offset
           ev[2 * NC + 1] = ev[2 * NC + 2] = ev[2 * NC + 3] = 0;
           int *sp = St + ((slot * 32 + pl) * g.DG + dgi[ps]) * SW;
 #pragma unroll
@@ -310,6 +310,8 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
     it_dg[k] = g.DG == 1 ? 0 : it_oc[k] / LPD;
   }
   const rsrc_t r_xt = make_rsrc(xt, (size_t)g.B * g.S_i * Cp * 2);
+  const rsrc_t r_gcol = make_rsrc(gcol, (size_t)g.B * g.K * g.S_o * Cp * 2);
+  const rsrc_t r_gout = make_rsrc(gout, (size_t)g.B * g.O * g.S_o * 2);
 
   // W^T[tap] fragments of this wave's channel block: resident for the whole pixel range
   U4 wf[NKS];
@@ -325,13 +327,16 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
 
   // ---- grad_out tile: item = (o, pixel octet); two items per thread in flight, tail loop.
   // (gb, gp) = image / pixel of the first pixel of the NEXT tile to load (wave-uniform) ----
-  const bool vec_ok = (g.S_o & 7) == 0;
+  const bool vec_ok = (g.S_o & 7) == 0, tile_ok = (g.S_o & 31) == 0;
   int gb = b_first, gp = p_first;
   auto load_item = [&](int item) -> U4 {
     const int o = item >> 2, oct = item & 3;
     int bb = gb, pp = gp + oct * 8;
     while (pp >= g.S_o) { pp -= g.S_o; ++bb; }
     U4 v = {0, 0, 0, 0};
+    // 32 | S_o: a tile never straddles two images -- row offset per thread, tile offset scalar, and
+    // images beyond the batch fall out of the buffer's range (no 64-bit address arithmetic per tile)
+    if (tile_ok) return buf_load4u(r_gout, o < g.O ? (o * g.S_o + oct * 8) * 2 : kHpOob, (gb * g.O * g.S_o + gp) * 2);
     if (o < g.O && bb < g.B) {
       if (vec_ok) {
         v = *reinterpret_cast<const U4 *>(gout + ((int64_t)bb * g.O + o) * g.S_o + pp);
@@ -438,8 +443,7 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
       };
       auto consume = [&](int k, int slot) {
         if (it_on[k]) {
-          if (grow[slot] >= 0)
-            *reinterpret_cast<U4 *>(gcol + (int64_t)grow[slot] * Cp + it_oc[k] * 8) = gq[slot];
+          buf_store4u(r_gcol, grow[slot] + it_oc[k] * 16, 0, gq[slot]);   // dead pixels: out of range, dropped
           float col[8], S[NC];
 #pragma unroll
           for (int j = 0; j < 8; ++j) col[j] = 0.f;
