@@ -209,8 +209,11 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
             ev[ci] = (f.live && hc.idx[ci] >= 0) ? (bb * g.S_i + hc.idx[ci]) * Cp * 2 : kHpOob;
             ev[NC + ci] = __float_as_int(f.live ? hc.w[ci] * ml[ps] : 0.f);
           }
-          ev[2 * NC] = f.live ? ((bb * g.K + tap) * g.S_o + pix) * Cp * 2 : kHpOob;   // grad_col row, byte offset
-          ev[2 * NC + 1] = ev[2 * NC + 2] = ev[2 * NC + 3] = 0;
+          // grad_col row: byte offset inside its image's rows (one image's rows stay below the chunk
+          // limit, a whole chunk's need not), and the image
+          ev[2 * NC] = f.live ? (tap * g.S_o + pix) * Cp * 2 : kHpOob;
+          ev[2 * NC + 1] = bb;
+          ev[2 * NC + 2] = ev[2 * NC + 3] = 0;
           int *sp = St + ((slot * 32 + pl) * g.DG + dgi[ps]) * SW;
 #pragma unroll
           for (int q = 0; q < SW; q += 4) *reinterpret_cast<int4 *>(sp + q) = make_int4(ev[q], ev[q + 1], ev[q + 2], ev[q + 3]);
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
     it_dg[k] = g.DG == 1 ? 0 : it_oc[k] / LPD;
   }
   const rsrc_t r_xt = make_rsrc(xt, (size_t)g.B * g.S_i * Cp * 2);
-  const rsrc_t r_gcol = make_rsrc(gcol, (size_t)g.B * g.K * g.S_o * Cp * 2);
+  const size_t gcol_img = (size_t)g.K * g.S_o * Cp;   // grad_col elements per image
   const rsrc_t r_gout = make_rsrc(gout, (size_t)g.B * g.O * g.S_o * 2);
 
   // W^T[tap] fragments of this wave's channel block: resident for the whole pixel range
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
   const int ngitems = OpL * 4;
   U4 gi0 = {0, 0, 0, 0}, gi1 = {0, 0, 0, 0};
   int sb = b_first, sp0 = p_first;   // position of the tile whose tail items g_store loads itself
+  int cb = b_first, cpx = p_first;   // image / pixel of the first pixel of the tile being processed
   auto g_load = [&]() {   // requests the tile at (gb, gp)
     if (tid < ngitems) gi0 = load_item(tid);
     if (tid + NTW < ngitems) gi1 = load_item(tid + NTW);
@@ -421,8 +425,9 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
       constexpr int NI = ND == 2 ? 2 : 1;
       U4 x[NI][NC], gq[NI];
       float wm[NI][NC];
-      int grow[NI];
+      int grow[NI], gimg[NI];
       const int *st_tile = St + buf * 32 * g.DG * SW;
+      const rsrc_t r_gcol = make_rsrc(gcol + (size_t)cb * gcol_img, gcol_img * 2);   // image of this tile (tile_ok)
       auto request = [&](int k, int slot) {
         if (it_on[k]) {
           const int *sp = st_tile + (it_p[k] * g.DG + it_dg[k]) * SW;
@@ -438,12 +443,16 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
             wm[slot][ci] = __int_as_float(ev[NC + ci]);
           }
           grow[slot] = ev[2 * NC];
+          gimg[slot] = ev[2 * NC + 1];
           gq[slot] = *reinterpret_cast<const U4 *>(Gc + it_p[k] * pitch_gc + it_oc[k] * 8);
         }
       };
       auto consume = [&](int k, int slot) {
         if (it_on[k]) {
-          buf_store4u(r_gcol, grow[slot] + it_oc[k] * 16, 0, gq[slot]);   // dead pixels: out of range, dropped
+          if (tile_ok)   // all pixels of the tile in one image: scalar base, dead pixels out of range (dropped)
+            buf_store4u(r_gcol, grow[slot] + it_oc[k] * 16, 0, gq[slot]);
+          else if (grow[slot] != kHpOob)
+            *reinterpret_cast<U4 *>(gcol + (size_t)gimg[slot] * gcol_img + (grow[slot] >> 1) + it_oc[k] * 8) = gq[slot];
           float col[8], S[NC];
 #pragma unroll
           for (int j = 0; j < 8; ++j) col[j] = 0.f;
@@ -497,6 +506,8 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
       }
     }
     HP_T(6);
+    cpx += 32;
+    while (cpx >= g.S_o) { cpx -= g.S_o; ++cb; }
   }
 #ifdef HP_TIMING
   if (lane == 0 && wave < 2)
