@@ -95,11 +95,12 @@ template <int ND> __device__ __forceinline__ void advance_pixel(const Geom &g, i
 }
 
 // Workgroup = WAVES worker waves (wave w = input channels [32w, 32w+32) in the matrix phases, the
-// (pixel, octet) items in the gather phase) + ONE state wave that runs the per-(tap, pixel) scalar
+// (pixel, octet) items in the gather phase) + NS state waves (two when DG > 2, i.e. more than 64
+// (pixel, deformable group) states per tile: the state pipeline is the critical path there) that run the per-(tap, pixel) scalar
 // pipeline -- offsets / mask, sampling state, CSR counting, the final grad_offset / grad_mask
 // arithmetic -- beside them (it was 47 % of the tile time when wave 0 did it on top of its share).
-template <int ND, bool MOD, typename T, int WAVES, int NKS>
-__global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_kernel(
+template <int ND, bool MOD, typename T, int WAVES, int NKS, int NS>
+__global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2_kernel(
     Geom g, HpDims hd, const typename T::Raw *__restrict__ xt, const U4 *__restrict__ wpb,
     const int4 *__restrict__ btab, const typename T::Raw *__restrict__ gout,
     const typename T::Raw *__restrict__ offset, const typename T::Raw *__restrict__ mask,
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
   constexpr int MB2 = NKS / 2;
   constexpr int NTW = 64 * WAVES;   // worker threads
   constexpr int SW = 2 * NC + 4;    // state dwords per (pixel, dg): voff[NC], w*mask[NC], grad_col row, pad
-  constexpr int SP = 2;             // (pixel, dg) states per lane of the state wave (DG <= 4)
+  constexpr int SP = 2 / NS;        // (pixel, dg) states per lane of a state wave (DG <= 4; NS = 2 state waves when DG > 2)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int OpL = hd.OpL, Cp = hd.Cp;
   const int pitch_gc = Cp + 8;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, pl = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_state = wave == WAVES;
+  const bool is_state = wave >= WAVES;
   const int cblk = wave;
   const bool active = !is_state && cblk < hd.cblks;
   const int tap = blockIdx.y, range = blockIdx.x;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
     // =====================================================================================
     // state wave
     // =====================================================================================
-    const int npass = (32 * g.DG + 63) / 64;
+    const int npass = (32 * g.DG + 64 * NS - 1) / (64 * NS);
     int tcd[ND];
     tap_coords<ND>(g, tap, tcd);
     // per-lane (pixel, dg) items; position of the pixel whose state is built NEXT
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(64 * (WAVES + 1), WAVES >= 8 ? 1 : 2) void hp_bwd2_
     int dgi[SP], nb[SP], noc[SP][ND];
 #pragma unroll
     for (int ps = 0; ps < SP; ++ps) {
-      const int x = lane + 64 * ps;
+      const int x = lane + 64 * (NS == 2 ? wave - WAVES : ps);
       on[ps] = ps < npass && x < 32 * g.DG;
       dgi[ps] = on[ps] ? x >> 5 : 0;
       nb[ps] = b_first;
@@ -546,18 +547,18 @@ size_t hp_bwd2_lds_bytes(const Geom &g, const HpDims &hd) {
          (size_t)2 * 32 * g.DG * (2 * nc + 4) * 4 + (size_t)32 * g.DG * msub * nc * 4;
 }
 
-template <int ND, bool MOD, typename T, int WAVES, int NKS>
+template <int ND, bool MOD, typename T, int WAVES, int NKS, int NS>
 static int launch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, const void *xt,
                           const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                           hipStream_t stream) {
   using Raw = typename T::Raw;
   const size_t lds = hp_bwd2_lds_bytes(g, hd);
   if (lds > 64 * 1024) {
-    hipError_t ea = hipFuncSetAttribute((const void *)hp_bwd2_kernel<ND, MOD, T, WAVES, NKS>,
+    hipError_t ea = hipFuncSetAttribute((const void *)hp_bwd2_kernel<ND, MOD, T, WAVES, NKS, NS>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; }
   }
-  hipLaunchKernelGGL((hp_bwd2_kernel<ND, MOD, T, WAVES, NKS>), dim3(hd.ranges, g.K), dim3(64 * (WAVES + 1)), lds,
+  hipLaunchKernelGGL((hp_bwd2_kernel<ND, MOD, T, WAVES, NKS, NS>), dim3(hd.ranges, g.K), dim3(64 * (WAVES + NS)), lds,
                      stream, g, hd, (const Raw *)xt, (const U4 *)wpb, btab, (const Raw *)t.grad_output,
                      (const Raw *)t.offset, (const Raw *)t.mask, (Raw *)gcol, (Raw *)t.grad_offset,
                      (Raw *)t.grad_mask, part, cnt);
@@ -568,7 +569,11 @@ template <int ND, bool MOD, typename T>
 static int dispatch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, const void *xt,
                             const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                             hipStream_t stream) {
-#define HP_BWD(W, N) return launch_bwd2_hp<ND, MOD, T, W, N>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream)
+#define HP_BWD(W, N)                                                                           \
+  do {                                                                                         \
+    if (g.DG > 2) return launch_bwd2_hp<ND, MOD, T, W, N, 2>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream); \
+    return launch_bwd2_hp<ND, MOD, T, W, N, 1>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream);              \
+  } while (0)
 #define HP_BWD_W(W)                                                                            \
   switch (hd.nks) {                                                                            \
     case 2: HP_BWD(W, 2);                                                                      \
