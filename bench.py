@@ -9,11 +9,18 @@ all-reduce over RCCL.
   --scaling weak   (default) B = 32 per GPU, global batch 32 N
   --scaling strong global B = 32, contiguous shards of 32 / N images per GPU (cfg2
                    at 32 / 16 / 8 / 4 images per GPU on 1 / 2 / 4 / 8 GPUs)
+  --graph          the step (forward + backward) is captured once in a HIP graph and replayed; the
+                   default for --scaling strong, where a 4-image shard (0.6 ms of kernels) is as
+                   much host-bound as kernel-bound when every launch is enqueued from Python
 
-    python bench.py --gpus N --steps K --warmup W [--scaling strong]
+    python bench.py --gpus N --steps K --warmup W [--scaling strong] [--graph]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings).
+`--gpus N` with N > 1 and no RANK in the environment re-executes itself under
+torch.distributed.run with N ranks (one per GPU); it exits non-zero when fewer than N GPUs are
+visible.  Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings); besides the
+headline it carries `other_configs`: the per-GPU shards of BASELINE.json configs[2..4] timed in
+the same process (N = 1 only).
 """
 import argparse
 import json
@@ -26,29 +33,125 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-# cfg2 of BASELINE.json
-B, C, O, H, W, KH, KW = 32, 256, 256, 56, 56, 3, 3
-K = KH * KW
-N_SAMPLES = B * C * K * H * W                      # 231 211 008 "samples" per GPU per step
-GEMM_FLOP = 2.0 * O * C * K * B * H * W            # one of the three GEMMs (118.4 GFLOP)
-PEAK_F32_MFMA_TFLOPS = 157.3                       # MI355X_MICROARCH.md, dense fp32 matrix peak
-# compulsory HBM bytes of one fwd+bwd step
-COMPULSORY_BYTES = 553_396_224
+# peaks: /opt/skills/guides/MI355X_MICROARCH.md (dense; no sparsity figures)
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
 
+# Per-GPU workloads of BASELINE.json configs[1..4].  `bytes` = compulsory HBM
+# bytes of one fwd+bwd step of this shard, `flop` = GEMM FLOP of the step (three GEMMs), `bound` =
+# the roofline SURVEY 8d assigns the whole op.
+WORKLOADS = {
+    "cfg2": dict(nd=2, modulated=True, B=32, C=256, O=256, sp=(56, 56), G=1, DG=1, dil=1, dtype="f32", bias=True,
+                 bytes=553_396_224, bound="mfma", peak=PEAK_F32_MFMA_TFLOPS,
+                 what="ModulatedDeformConv2d 3x3, C_in=C_out=256, 56x56, deformable_group=1, fp32"),
+    "cfg3": dict(nd=2, modulated=True, B=32, C=256, O=256, sp=(56, 56), G=32, DG=4, dil=1, dtype="f16", bias=False,
+                 bytes=2_575_545_344 // 8, bound="hbm", peak=HBM_PEAK_GBS,
+                 what="ModulatedDeformConv2d 3x3, C=256, 56x56, group=32, deformable_group=4, fp16 (1/8 of B=256)"),
+    "cfg4": dict(nd=3, modulated=False, B=8, C=64, O=64, sp=(32, 32, 32), G=1, DG=1, dil=1, dtype="f32", bias=False,
+                 bytes=591_675_904, bound="mfma", peak=PEAK_F32_MFMA_TFLOPS,
+                 what="DeformConv3d 3x3x3, C=64, 32^3, fp32"),
+    "cfg5": dict(nd=3, modulated=True, B=8, C=128, O=128, sp=(16, 64, 64), G=1, DG=1, dil=2, dtype="f16", bias=False,
+                 bytes=4_045_963_776 // 4, bound="mfma", peak=PEAK_F16_MFMA_TFLOPS,
+                 what="ModulatedDeformConv3d 3x3x3, C=128, 16x64x64, dilation=2, fp16 (1/4 of B=32)"),
+}
 
-def make_inputs(device, batch=B):
-    g = torch.Generator(device="cpu").manual_seed(0)
-    rn = lambda *s: torch.randn(*s, generator=g)
-    x = rn(batch, C, H, W)
-    off = rn(batch, 2 * K, H, W)
-    m = torch.sigmoid(rn(batch, K, H, W))
-    w = (torch.rand(O, C, KH, KW, generator=g) * 2 - 1) / math.sqrt(C * K)
-    b = 0.1 * rn(O)
-    go = rn(batch, O, H, W)
-    return [t.to(device).contiguous() for t in (x, off, m, w, b, go)]
+
+class Workload:
+    """Synthetic inputs of one configuration resident on `device` + closures for forward / backward
+    through the MDCONV_CUDA entry points (the reference's positional signatures)."""
+
+    def __init__(self, name, device, batch=None):
+        import torch
+        from modulated_deform_conv_amd import MDCONV_CUDA as M
+        cfg = dict(WORKLOADS[name])
+        self.name, self.cfg = name, cfg
+        nd, B = cfg["nd"], batch or cfg["B"]
+        C, O, sp, G, DG = cfg["C"], cfg["O"], cfg["sp"], cfg["G"], cfg["DG"]
+        K = 3 ** nd
+        self.B, self.K = B, K
+        self.scale = B / cfg["B"]                       # work relative to the nominal shard
+        self.n_samples = B * C * K * math.prod(sp)
+        self.gemm_flop = 2.0 * O * (C // G) * K * B * math.prod(sp)   # ONE of the three GEMMs
+        self.bytes = cfg["bytes"] * self.scale
+        dt = {"f32": torch.float32, "f16": torch.float16}[cfg["dtype"]]
+        g = torch.Generator(device="cpu").manual_seed(0)
+        rn = lambda *s: torch.randn(*s, generator=g)
+        mv = lambda t: t.to(device=device, dtype=dt).contiguous()
+        self.x = mv(rn(B, C, *sp))
+        self.off = mv(rn(B, DG * nd * K, *sp))
+        self.m = mv(torch.sigmoid(rn(B, DG * K, *sp))) if cfg["modulated"] else None
+        self.w = mv((torch.rand(O, C // G, *([3] * nd), generator=g) * 2 - 1) / math.sqrt(C * K))
+        self.b = mv(0.1 * rn(O)) if cfg["bias"] else self.x.new_empty(0)
+        self.go = mv(rn(B, O, *sp))
+        d = cfg["dil"]
+        self.geo = (3,) * nd + (1,) * nd + (d,) * nd + (d,) * nd + (G, DG, 64, cfg["bias"])
+        self.M = M
+        if not (nd == 2 and cfg["modulated"]):
+            # caller-allocated entry points (reference deformable_conv3d.cu:160-167, 434-442 ...)
+            self.out = torch.empty_like(self.go)
+            self.gi, self.gw, self.gb = torch.empty_like(self.x), torch.empty_like(self.w), torch.empty_like(self.b)
+            self.goff = torch.empty_like(self.off)
+            self.gm = torch.empty_like(self.m) if self.m is not None else None
+
+    def shard(self, lo, hi):
+        for k in ("x", "off", "m", "go"):
+            t = getattr(self, k)
+            if t is not None:
+                setattr(self, k, t[lo:hi].contiguous())
+        self.scale *= (hi - lo) / self.B
+        self.n_samples = self.n_samples // self.B * (hi - lo)
+        self.gemm_flop *= (hi - lo) / self.B
+        self.bytes *= (hi - lo) / self.B
+        self.B = hi - lo
+
+    def forward(self):
+        M, c = self.M, self.cfg
+        if c["nd"] == 2 and c["modulated"]:
+            return M.modulated_deform_conv2d_forward_cuda(self.x, self.w, self.b, self.off, self.m, *self.geo)
+        if c["modulated"]:
+            M.modulated_deform_conv3d_forward_cuda(self.x, self.w, self.b, self.off, self.m, self.out, *self.geo)
+        else:
+            M.deform_conv3d_forward_cuda(self.x, self.w, self.b, self.off, self.out, *self.geo)
+        return self.out
+
+    def backward(self):
+        """-> (grad_weight, grad_bias)"""
+        from modulated_deform_conv_amd import _capi
+        M, c = self.M, self.cfg
+        if c["nd"] == 2 and c["modulated"]:
+            r = M.modulated_deform_conv2d_backward_cuda(self.x, self.w, self.b, self.off, self.m, self.go, *self.geo)
+            return r[3], r[4]
+        with _capi.overwrite_grads():
+            if c["modulated"]:
+                M.modulated_deform_conv3d_backward_cuda(self.x, self.w, self.b, self.off, self.m, self.gi, self.gw,
+                                                        self.gb, self.goff, self.gm, self.go, *self.geo)
+            else:
+                M.deform_conv3d_backward_cuda(self.x, self.w, self.b, self.off, self.gi, self.gw, self.gb,
+                                              self.goff, self.go, *self.geo)
+        return self.gw, self.gb
+
+
+def resolve_world(gpus, env, visible_gpus):
+    """How this invocation runs.  -> ("spawn", N): re-execute under torch.distributed.run with N ranks;
+    ("run", world, rank, local_rank): run as that rank.  Raises SystemExit (non-zero) when the
+    request cannot be met -- it never silently runs fewer ranks than `--gpus` asked for."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" in env:
+        world, rank = int(env.get("WORLD_SIZE", "1")), int(env["RANK"])
+        local = int(env.get("LOCAL_RANK", "0"))
+        if world != gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (gpus, world))
+        if visible_gpus is not None and local >= visible_gpus:
+            raise SystemExit("bench.py: rank %d needs GPU %d but only %d GPU(s) are visible" % (rank, local, visible_gpus))
+        return ("run", world, rank, local)
+    if visible_gpus is not None and visible_gpus < gpus:
+        raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible on this node; "
+                         "refusing to print a mislabeled %d-GPU line" % (gpus, visible_gpus, visible_gpus))
+    if gpus == 1:
+        return ("run", 1, 0, 0)
+    return ("spawn", gpus)
 
 
 def kernel_sources_sha16():
@@ -84,7 +187,7 @@ def measured_traffic(kernel):
     return None, src
 
 
-def cpu_baseline(batch=B, iters=3):
+def cpu_baseline(iters=3):
     """The oracle (CPU restatement of the reference, kind = "port") on a bounded sample of the
     same workload: cfg2 at its full B = 32, `iters` forward + backward passes, median reported.
     im2col and the three GEMMs use every host thread OpenMP provides; the per-sample gradient
@@ -92,19 +195,61 @@ def cpu_baseline(batch=B, iters=3):
     its accumulation order is the reference's sequential one."""
     import oracle
     oracle.build()
-    x, off, m, w, b, go = make_inputs("cpu", batch)
+    wl = Workload("cfg2", "cpu")
     times = []
     for _ in range(iters):
         t0 = time.perf_counter()
-        oracle.forward(oracle.MDCN2D, x, w, b, off, m, 1, 1, 1, 1, 1, 64)
-        oracle.backward(oracle.MDCN2D, x, w, b, off, m, go, 1, 1, 1, 1, 1, 64)
+        oracle.forward(oracle.MDCN2D, wl.x, wl.w, wl.b, wl.off, wl.m, 1, 1, 1, 1, 1, 64)
+        oracle.backward(oracle.MDCN2D, wl.x, wl.w, wl.b, wl.off, wl.m, wl.go, 1, 1, 1, 1, 1, 64)
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
-    return {"value": batch * C * K * H * W / dt / 1e9, "unit": "GSamples/s",
+    return {"value": wl.n_samples / dt / 1e9, "unit": "GSamples/s",
             "cores": oracle.num_threads(), "kind": "port",
             "sample": "cfg2 at B=%d, %d x (fwd+bwd), median %.1f s per iteration (all: %s); %d OpenMP "
                       "threads for im2col + GEMMs, 1 thread for the per-sample gradient loop"
-                      % (batch, iters, dt, ", ".join("%.1f" % t for t in times), oracle.num_threads())}
+                      % (wl.B, iters, dt, ", ".join("%.1f" % t for t in times), oracle.num_threads())}
+
+
+def time_other_config(name, device, steps=5, warmup=2):
+    """Forward / backward of one of the other BASELINE.json configurations (its per-GPU shard) in
+    this process: HIP-event time of `steps` forward and `steps` backward passes, the in-library
+    per-kernel events, and the whole-step fraction of the roofline SURVEY.md 8d assigns it."""
+    import torch
+    from modulated_deform_conv_amd import _capi
+    wl = Workload(name, device)
+    for _ in range(warmup):
+        wl.forward(); wl.backward()
+    torch.cuda.synchronize()
+    _capi.profile_enable(True)
+    _capi.profile_reset()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    for _ in range(steps):
+        wl.forward()
+    ev[1].record()
+    for _ in range(steps):
+        wl.backward()
+    ev[2].record()
+    torch.cuda.synchronize()
+    _capi.profile_enable(False)
+    prof = _capi.profile_read()
+    f_ms, b_ms = ev[0].elapsed_time(ev[1]) / steps, ev[1].elapsed_time(ev[2]) / steps
+    t = (f_ms + b_ms) * 1e-3
+    c = wl.cfg
+    if c["bound"] == "hbm":
+        achieved, unit = wl.bytes / t / 1e9, "GB/s"
+    else:
+        achieved, unit = 3 * wl.gemm_flop / t / 1e12, "TFLOP/s"
+    res = {"workload": "%s, B=%d per GPU, forward+backward" % (c["what"], wl.B), "dtype": c["dtype"],
+           "fwd_ms": round(f_ms, 4), "bwd_ms": round(b_ms, 4), "ms_per_step": round(f_ms + b_ms, 4),
+           "GSamples_per_s": round(wl.n_samples / t / 1e9, 2), "kernel_path": _capi.last_kernels(),
+           "roofline": {"bound": c["bound"], "achieved": round(achieved, 2), "peak": c["peak"], "unit": unit,
+                        "frac": round(achieved / c["peak"], 4), "scope": "whole step",
+                        "compulsory_bytes": int(wl.bytes), "gemm_flop": 3 * wl.gemm_flop},
+           "kernels_ms": {k: round(v[1], 4) for k, v in prof.items()}}
+    del wl
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -113,16 +258,31 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay the step from a HIP graph (default for --scaling strong)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # under torchrun (RANK set) the collective path is exercised even with one process
-    distributed = world > 1 or (os.environ.get("MDCONV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    import torch
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    plan = resolve_world(args.gpus, os.environ, visible)
+    if plan[0] == "spawn":
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(plan[1]),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+    _, world, rank, local_rank = plan
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    use_graph = args.graph if args.graph is not None else args.scaling == "strong"
+    # under torchrun (RANK set) the collective path is exercised even with one process
+    distributed = world > 1 or (os.environ.get("MDCONV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
@@ -132,35 +292,57 @@ def main():
             os.environ["NCCL_DEBUG"] = "WARN"   # the image's default prints a banner on stdout
         dist.init_process_group("nccl", device_id=device)
 
-    from modulated_deform_conv_amd import MDCONV_CUDA as M, _capi
-    from modulated_deform_conv_amd.distributed import FusedGradAllReduce
-    x, off, m, w, b, go = make_inputs(device)
+    from modulated_deform_conv_amd import _capi
+    from modulated_deform_conv_amd.distributed import FusedGradAllReduce, shard_bounds
+    wl = Workload("cfg2", device)
+    nominal_b = wl.B
     if args.scaling == "strong":
         # global batch 32: this rank's contiguous shard
-        from modulated_deform_conv_amd.distributed import shard_bounds
-        lo, hi = shard_bounds(B, world, rank)
+        lo, hi = shard_bounds(wl.B, world, rank)
         if hi <= lo:
-            raise SystemExit("--scaling strong needs world size <= %d" % B)
-        x, off, m, go = (t[lo:hi].contiguous() for t in (x, off, m, go))
-    local_b = x.shape[0]
-    geo = (KH, KW, 1, 1, 1, 1, 1, 1, 1, 1, 64, True)
+            raise SystemExit("--scaling strong needs world size <= %d" % wl.B)
+        wl.shard(lo, hi)
     reducer = FusedGradAllReduce() if distributed else None
 
+    def compute():
+        out = wl.forward()
+        gw, gb = wl.backward()
+        return out, gw, gb
+
+    graph = None
+    if use_graph:
+        # capture forward + backward once (plain kernel sequences on the capturing stream, scratch from
+        # the graph's private pool); the exchange stays outside the graph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                compute()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static = compute()
+
     def step():
-        out = M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo)
-        gi, goff, gm, gw, gb = M.modulated_deform_conv2d_backward_cuda(x, w, b, off, m, go, *geo)
+        if graph is not None:
+            graph.replay()
+            if reducer is not None:
+                reducer(static[1], static[2])      # after the replay, on the same stream
+            return
+        _, gw, gb = compute()
         if reducer is not None:
             # RCCL all-reduce of grad_weight || grad_bias on a side stream, released as soon as
             # GEMM-2 / grad_bias are done, i.e. under the grad_input gather of the same backward
             reducer.reduce_overlapped(gw, gb)
-        return out, gi
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     paths = _capi.last_path()
-    _capi.profile_enable(True)
-    _capi.profile_reset()
+    if graph is None:
+        _capi.profile_enable(True)
+        _capi.profile_reset()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -170,12 +352,23 @@ def main():
     for i in range(args.steps):
         step()
         marks[i + 1].record()
+    t_enq = time.perf_counter()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    _capi.profile_enable(False)
-    prof = _capi.profile_read()
+    if graph is None:
+        _capi.profile_enable(False)
+        prof, prof_src = _capi.profile_read(), "HIP events around each kernel inside the timed region"
+    else:
+        # event records do not time anything inside a graph: per-kernel averages from eager steps
+        _capi.profile_enable(True)
+        _capi.profile_reset()
+        for _ in range(5):
+            compute()
+        torch.cuda.synchronize()
+        _capi.profile_enable(False)
+        prof, prof_src = _capi.profile_read(), "HIP events around each kernel, 5 eager steps after the timed (graph) region"
 
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -188,35 +381,40 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    global_b = B * world if args.scaling == "weak" else B
-    value = global_b * C * K * H * W / (elapsed / args.steps) / 1e9
-    flop_scale = local_b / B   # work of one launch on this rank relative to the B = 32 figures
-    # dominant kernel = the MFMA GEMM kernel with the largest measured average duration
-    dom, (dom_n, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1])
-    achieved = GEMM_FLOP * flop_scale / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    global_b = nominal_b * world if args.scaling == "weak" else nominal_b
+    value = global_b * (wl.n_samples // wl.B) / (elapsed / args.steps) / 1e9
+    # dominant kernel = the profiled kernel with the largest measured average duration
+    gemms = {k: v for k, v in prof.items() if "col2im" not in k}
+    dom, (dom_n, dom_ms) = max(gemms.items(), key=lambda kv: kv[1][1])
+    achieved = wl.gemm_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     traffic, traffic_src = measured_traffic(dom)
+    comp = wl.bytes
     result = {
         "metric": "fwd+bwd GSamples/s, MDCN2d 3x3 C=256 56x56 B=32; %HBM roofline",
         "value": round(value, 3), "unit": "GSamples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "ms_per_step_median": round(step_ms[len(step_ms) // 2], 4),
+        "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4),
+        "launch_mode": "hip graph replay" if graph is not None else "eager (one Python call per entry point)",
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "ModulatedDeformConv2d 3x3, C_in=C_out=256, 56x56, B=%d per GPU, "
-                               "deformable_group=1, fp32, forward+backward (BASELINE.json configs[1])"
-                               % local_b,
+        "config": {"workload": "%s, B=%d per GPU, forward+backward (BASELINE.json configs[1])" % (wl.cfg["what"], wl.B),
                    "global_batch": global_b, "parallelism": "dp%d batch-sharded" % world,
                    "kernel_path": paths},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                      "traffic_source": traffic_src,
-                     "flop_per_launch": GEMM_FLOP * flop_scale, "avg_ms": round(dom_ms, 4), "launches": dom_n},
-        "kernels_ms": {k: round(v[1], 4) for k, v in prof.items()},
-        "hbm_roofline": {"compulsory_bytes": int(COMPULSORY_BYTES * flop_scale),
-                         "achieved_GBs": round(COMPULSORY_BYTES * flop_scale / (ms_per_step * 1e-3) / 1e9, 1),
+                     "flop_per_launch": wl.gemm_flop, "avg_ms": round(dom_ms, 4), "launches": dom_n},
+        "kernels_ms": {k: round(v[1], 4) for k, v in prof.items()}, "kernels_ms_source": prof_src,
+        "hbm_roofline": {"compulsory_bytes": int(comp),
+                         "achieved_GBs": round(comp / (ms_per_step * 1e-3) / 1e9, 1),
                          "peak_GBs": HBM_PEAK_GBS,
-                         "frac": round(COMPULSORY_BYTES * flop_scale / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "frac": round(comp / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+    if world == 1 and not distributed and not args.no_other_configs:
+        del wl
+        torch.cuda.empty_cache()
+        result["other_configs"] = {n: time_other_config(n, device) for n in ("cfg3", "cfg4", "cfg5")}
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     print(json.dumps(result))

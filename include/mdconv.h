@@ -95,12 +95,15 @@ int mdconv_last_path(void);
 enum { MDCONV_KERNELS_DIRECT = 1, MDCONV_KERNELS_F32 = 2, MDCONV_KERNELS_HP = 3 };
 int mdconv_last_kernels(void);
 
-/* Per-kernel timing for benchmarks: when enabled, the three MFMA GEMM kernels are bracketed by HIP
+/* Per-kernel timing for benchmarks: when enabled, the four dominant kernels are bracketed by HIP
  * events ON THE CALLER'S STREAM.  After a stream/device synchronise, mdconv_profile_read() returns
- * the number of launches of kernel `which` (0 = forward GEMM, 1 = backward data GEMM,
- * 2 = backward weight GEMM) recorded since the last reset and their total duration in ms. */
+ * the number of launches of kernel `which` (0 = forward GEMM, 1 = backward data GEMM [the fused
+ * backward kernel of the 16-bit path], 2 = backward weight GEMM, 3 = grad_input gather) recorded
+ * since the last reset and their total duration in ms; mdconv_profile_name() the name of the kernel
+ * variant that ran in that slot last (as rocprofv3 prints it, without template arguments). */
 int mdconv_profile_enable(int on);
 int mdconv_profile_read(int which, double *total_ms);
+const char *mdconv_profile_name(int which);
 void mdconv_profile_reset(void);
 
 /* Backward write mode of the calling thread: 1 (default) = ACCUMULATE into grad_* like the
@@ -117,6 +120,11 @@ int mdconv_set_accumulate(int on);
  * grad_input included, keeps the reference layout.  Returns the previous setting. */
 enum { MDCONV_LAYOUT_NCHW = 0, MDCONV_LAYOUT_CHANNELS_LAST = 1 };
 int mdconv_set_input_layout(int layout);
+/* 1 if the forward (backward = 0) / backward (backward = 1) of `d` accepts `input` in `layout`,
+ * else 0.  The two directions differ (the native 16-bit backward covers fewer shapes than the
+ * forward), so a caller that saved a channels-last input for its backward asks here and makes a
+ * contiguous copy when the answer is 0 (modulated_deform_conv_amd/MDCONV_CUDA.py does). */
+int mdconv_input_layout_supported(const mdconv_desc *d, int layout, int backward);
 
 /* Multi-GPU overlap: every backward records an event on its stream as soon
  * as grad_weight and grad_bias are final -- before the grad_input gather is enqueued.
@@ -126,7 +134,10 @@ int mdconv_set_input_layout(int layout);
  * the all-reduce of grad_weight || grad_bias runs under the rest of the backward.
  * mdconv_stream_wait_weight_ready() is the stream-less form: the most recent backward on the
  * current device (use the keyed form when several streams run backwards concurrently).
- * Both return MDCONV_EINVAL if no such backward has been issued. */
+ * Both return MDCONV_EINVAL if no such backward has been issued.  The library keeps one event per
+ * (device, stream handle) for the most recently used streams (64 per process; older entries are
+ * destroyed).  A stream handle the runtime recycles after hipStreamDestroy matches the event of the
+ * destroyed stream until the first backward on the new one: wait only for backwards you issued. */
 int mdconv_stream_wait_weight_ready(void *stream);
 int mdconv_stream_wait_weight_ready_on(void *stream, void *producer_stream);
 

@@ -71,6 +71,16 @@ def _desc(nd, modulated, input, weight, ksz, stride, pad, dil, group, deformable
     return d
 
 
+def _layout(d, input, backward):
+    """A channels-last `input` stays as it is where the kernels of this direction gather from that
+    layout (include/mdconv.h: mdconv_input_layout_supported -- the native 16-bit backward covers
+    fewer shapes than the forward, and MDCONV_PATH / MDCONV_HP can switch those kernels off);
+    otherwise the call runs on a contiguous copy, like any other PyTorch operator would."""
+    if input.is_contiguous() or _capi.lib().mdconv_input_layout_supported(ctypes.byref(d), 1, int(backward)):
+        return input
+    return input.contiguous()
+
+
 def _out_shape(d, nd):
     L = _capi.lib()
     return tuple(L.mdconv_out_size(ctypes.byref(d), a) for a in range(nd))
@@ -131,6 +141,7 @@ def _forward(nd, modulated, fn_name, input, weight, bias, offset, mask, output, 
     _check_contig(**tensors)
     d = _desc(nd, modulated, input, weight, ksz, stride, pad, dil, group, deformable_group, in_step,
               with_bias)
+    input = _layout(d, input, False)
     osz = _out_shape(d, nd)
     _check_side(d, nd, _prod(ksz), offset, mask if modulated else None, output, "output", osz)
     _same(input, weight=weight, offset=offset, mask=mask if modulated else None,
@@ -168,6 +179,7 @@ def deform_conv2d_backward_cuda(input, weight, bias, offset, grad_input, grad_we
                   grad_output=grad_output)
     d = _desc(2, False, input, weight, (kernel_h, kernel_w), (stride_h, stride_w), (pad_h, pad_w),
               (dilation_h, dilation_w), group, deformable_group, in_step, with_bias)
+    input = _layout(d, input, True)
     osz = _out_shape(d, 2)
     _check_side(d, 2, kernel_h * kernel_w, offset, None, grad_output, "grad_output", osz)
     _backward_checks(input, weight, offset, None, grad_input, grad_weight, grad_bias, grad_offset,
@@ -210,6 +222,7 @@ def modulated_deform_conv2d_backward_cuda(input, weight, bias, offset, mask, gra
     grad_output = grad_output.contiguous()
     d = _desc(2, True, input, weight, (kernel_h, kernel_w), (stride_h, stride_w), (pad_h, pad_w),
               (dilation_h, dilation_w), group, deformable_group, in_step, with_bias)
+    input = _layout(d, input, True)
     osz = _out_shape(d, 2)
     _check_side(d, 2, kernel_h * kernel_w, offset, mask, grad_output, "grad_output", osz)
     # the reference allocates zeros here (mdeformable_conv.cu:404-411) and adds into them; this
@@ -252,6 +265,7 @@ def deform_conv3d_backward_cuda(input, weight, bias, offset, grad_input, grad_we
     ksz = (kernel_h, kernel_w, kernel_l)
     d = _desc(3, False, input, weight, ksz, (stride_h, stride_w, stride_l), (pad_h, pad_w, pad_l),
               (dilation_h, dilation_w, dilation_l), group, deformable_group, in_step, with_bias)
+    input = _layout(d, input, True)
     osz = _out_shape(d, 3)
     _check_side(d, 3, _prod(ksz), offset, None, grad_output, "grad_output", osz)
     _backward_checks(input, weight, offset, None, grad_input, grad_weight, grad_bias, grad_offset,
@@ -288,6 +302,7 @@ def modulated_deform_conv3d_backward_cuda(input, weight, bias, offset, mask, gra
     ksz = (kernel_h, kernel_w, kernel_l)
     d = _desc(3, True, input, weight, ksz, (stride_h, stride_w, stride_l), (pad_h, pad_w, pad_l),
               (dilation_h, dilation_w, dilation_l), group, deformable_group, in_step, with_bias)
+    input = _layout(d, input, True)
     osz = _out_shape(d, 3)
     _check_side(d, 3, _prod(ksz), offset, mask, grad_output, "grad_output", osz)
     _backward_checks(input, weight, offset, mask, grad_input, grad_weight, grad_bias, grad_offset,

@@ -15,8 +15,9 @@ PATH_AUTO, PATH_DIRECT, PATH_MFMA = 0, 1, 2
 EXPORTS = (
     "mdconv_abi_version", "mdconv_last_error", "mdconv_out_size", "mdconv_workspace_bytes",
     "mdconv_set_path", "mdconv_last_path", "mdconv_last_kernels",
-    "mdconv_profile_enable", "mdconv_profile_read", "mdconv_profile_reset",
+    "mdconv_profile_enable", "mdconv_profile_read", "mdconv_profile_reset", "mdconv_profile_name",
     "mdconv_stream_wait_weight_ready", "mdconv_stream_wait_weight_ready_on", "mdconv_set_accumulate", "mdconv_set_input_layout",
+    "mdconv_input_layout_supported",
     "mdconv_deform_conv2d_forward", "mdconv_deform_conv2d_backward",
     "mdconv_modulated_deform_conv2d_forward", "mdconv_modulated_deform_conv2d_backward",
     "mdconv_deform_conv3d_forward", "mdconv_deform_conv3d_backward",
@@ -56,6 +57,8 @@ def lib():
         L.mdconv_profile_enable.restype = ctypes.c_int
         L.mdconv_profile_read.restype = ctypes.c_int
         L.mdconv_profile_reset.restype = None
+        L.mdconv_profile_name.restype = ctypes.c_char_p
+        L.mdconv_profile_name.argtypes = [ctypes.c_int]
         L.mdconv_set_accumulate.restype = ctypes.c_int
         L.mdconv_set_accumulate.argtypes = [ctypes.c_int]
         L.mdconv_set_input_layout.restype = ctypes.c_int
@@ -65,7 +68,8 @@ def lib():
         L.mdconv_stream_wait_weight_ready_on.restype = ctypes.c_int
         L.mdconv_stream_wait_weight_ready_on.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.mdconv_last_kernels.restype = ctypes.c_int
-        for name in EXPORTS[10:]:
+        L.mdconv_input_layout_supported.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        for name in EXPORTS[11:]:
             getattr(L, name).restype = ctypes.c_int
         if L.mdconv_abi_version() != 1:
             raise ImportError("libmdconv_hip.so ABI version mismatch")
@@ -93,7 +97,7 @@ def last_kernels():
     return {0: "none", 1: "direct", 2: "f32", 3: "hp"}[lib().mdconv_last_kernels()]
 
 
-PROFILE_KERNELS = {0: "mfma_fwd_kernel", 1: "mfma_bwd_data_kernel", 2: "mfma_bwd_weight_kernel"}
+PROFILE_SLOTS = 4   # forward GEMM, backward data GEMM, backward weight GEMM, grad_input gather
 
 
 class overwrite_grads:
@@ -148,8 +152,10 @@ def profile_reset():
 def profile_read():
     """{kernel name: (launches, average ms)} -- call after torch.cuda.synchronize()."""
     out = {}
-    for which, name in PROFILE_KERNELS.items():
+    for which in range(PROFILE_SLOTS):
         tot = ctypes.c_double(0)
         n = lib().mdconv_profile_read(which, ctypes.byref(tot))
-        out[name] = (n, tot.value / n if n else 0.0)
+        name = lib().mdconv_profile_name(which).decode()
+        if n and name:
+            out[name] = (n, tot.value / n)
     return out

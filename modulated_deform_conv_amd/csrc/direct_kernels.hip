@@ -39,6 +39,13 @@ template <> struct PairLoad<__half> {
     y = __half2float(__ushort_as_half((unsigned short)(bits >> 16)));
   }
 };
+template <> struct PairLoad<bf16_t> {
+  static __device__ __forceinline__ void ld(rsrc_t r, unsigned voff, float &x, float &y) {
+    const unsigned bits = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0);
+    x = __uint_as_float(bits << 16);
+    y = __uint_as_float(bits & 0xffff0000u);
+  }
+};
 template <> struct PairLoad<double> {
   static __device__ __forceinline__ void ld(rsrc_t r, unsigned voff, double &x, double &y) {
     struct D2 { double x, y; };
@@ -474,6 +481,7 @@ int direct_forward(const Geom &g, int dtype, const Tensors &t, hipStream_t strea
     case MDCONV_F32: return dispatch_fwd<float>(g, t, stream);
     case MDCONV_F16: return dispatch_fwd<__half>(g, t, stream);
     case MDCONV_F64: return dispatch_fwd<double>(g, t, stream);
+    case MDCONV_BF16: return dispatch_fwd<bf16_t>(g, t, stream);
   }
   set_error("unknown dtype %d", dtype);
   return MDCONV_EINVAL;
@@ -484,6 +492,7 @@ int direct_backward(const Geom &g, int dtype, const Tensors &t, hipStream_t stre
     case MDCONV_F32: return dispatch_bwd<float>(g, t, stream, parts);
     case MDCONV_F16: return dispatch_bwd<__half>(g, t, stream, parts);
     case MDCONV_F64: return dispatch_bwd<double>(g, t, stream, parts);
+    case MDCONV_BF16: return dispatch_bwd<bf16_t>(g, t, stream, parts);
   }
   set_error("unknown dtype %d", dtype);
   return MDCONV_EINVAL;

@@ -144,6 +144,7 @@ struct HpDims {
   int MB2;          // GEMM-2 output-channel blocks per 32-channel block
   int waves;        // waves per workgroup of the fused backward kernel = cblks (<= 8)
   int ranges;       // pixel ranges per tap (split-K of grad_weight)
+  int max_ranges;   // upper bound of `ranges` for ANY batch size of this geometry (workspace sizing)
   int tiles_per_range;
   int ntiles;       // 32-pixel tiles
 };

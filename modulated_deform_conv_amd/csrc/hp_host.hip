@@ -47,7 +47,7 @@ Geom chunk_geom(const Geom &g, int bc) {
 }
 
 struct FwdLayout { size_t off_xt, off_w, off_tab, total; };
-struct BwdLayout { size_t off_xt, off_w, off_tab, off_gcol, off_part, off_cnt, off_rowptr, off_entries, total; };
+struct BwdLayout { size_t off_xt, off_w, off_tab, off_gcol, off_part, off_gw32, off_cnt, off_rowptr, off_entries, total; };
 
 // images per chunk: channels-last input copy (and one image's grad_col) below the limit
 int chunk_batch(const Geom &g, const HpDims &hd, bool backward) {
@@ -78,7 +78,10 @@ BwdLayout bwd_layout(const Geom &gc, const HpDims &hd) {
   L.off_w = off;    off += align_up((size_t)gc.K * hd.cblks * hd.nks * 1024);
   L.off_tab = off;  off += align_up((size_t)hd.cblks * sizeof(int4));
   L.off_gcol = off; off += align_up((size_t)gc.B * gc.K * gc.S_o * hd.Cp * 2);
-  L.off_part = off; off += align_up((size_t)gc.K * hd.ranges * hd.cblks * hd.MB2 * 4096);
+  // a shorter last chunk can have MORE ranges than a full one (ranges is not monotonic in the tile
+  // count), so the partials are sized for the bound; gw32 = running fp32 grad_weight over chunks
+  L.off_part = off; off += align_up((size_t)gc.K * hd.max_ranges * hd.cblks * hd.MB2 * 4096);
+  L.off_gw32 = off; off += align_up((size_t)gc.O * gc.Cg * gc.K * sizeof(float));
   // scatter lists: one 32-byte entry per sample, keyed by its extended anchor (hp_col2im.hip)
   const size_t S_e = (size_t)hp_anchor_space(gc);
   L.off_cnt = off;  off += align_up((size_t)gc.B * gc.DG * S_e * sizeof(int));
@@ -139,6 +142,7 @@ HpDims hp_dims(const Geom &g) {
   const int slots = num_cus() * (hd.waves >= 8 ? 1 : 2 * (4 / hd.waves));
   int ranges = slots / g.K;
   if (ranges < 1) ranges = 1;
+  hd.max_ranges = ranges;
   if (ranges > hd.ntiles) ranges = hd.ntiles;
   hd.tiles_per_range = (hd.ntiles + ranges - 1) / ranges;
   hd.ranges = (hd.ntiles + hd.tiles_per_range - 1) / hd.tiles_per_range;
@@ -203,10 +207,11 @@ int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t
     const void *xt = base + L.off_xt;
     if (g.in_cl) xt = (const char *)t.input + (size_t)b0 * g.S_i * g.C * 2;   // already channels-last
     else if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
-    profile_mark(0, true, stream);
     // quad-contiguous gathers (hp_fwd2.hip) unless a 64-channel stage would straddle deformable groups
     static const int fwd_ver = getenv("MDCONV_HP_FWD") ? atoi(getenv("MDCONV_HP_FWD")) : 2;
-    if (fwd_ver == 2 && (g.DG == 1 || (g.Cdg % 64 == 0 && fwd2_rows_align(g, hd))))
+    const bool fwd2 = fwd_ver == 2 && (g.DG == 1 || (g.Cdg % 64 == 0 && fwd2_rows_align(g, hd)));
+    profile_mark(0, true, stream, fwd2 ? "hp_fwd2_kernel" : "hp_fwd_kernel");
+    if (fwd2)
       rc = hp_forward2_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                               (const int2 *)(base + L.off_tab), stream);
     else
@@ -233,7 +238,7 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
   for (int b0 = 0; b0 < g.B; b0 += Bc) {
     const int bc = g.B - b0 < Bc ? g.B - b0 : Bc;
     Geom gc = chunk_geom(g, bc);
-    gc.acc_w = b0 > 0 ? 1 : g.acc_w;
+    const bool multi = Bc < g.B, first = b0 == 0, last = b0 + bc >= g.B;
     const HpDims hd = hp_dims(gc);
     Tensors tc = t;
     tc.input = (const char *)t.input + (size_t)b0 * g.C * g.S_i * 2;
@@ -248,9 +253,10 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
     if (g.in_cl) xt = (const char *)t.input + (size_t)b0 * g.S_i * g.C * 2;   // already channels-last
     else if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
     if ((rc = hp_csr_zero(gc, cnt, stream))) return rc;
-    profile_mark(1, true, stream);
     static const int bwd_ver = getenv("MDCONV_HP_BWD") ? atoi(getenv("MDCONV_HP_BWD")) : 2;
-    if (bwd_ver == 2 && g.DG <= 4 && hp_bwd2_lds_bytes(gc, hd) <= 160 * 1024)
+    const bool bwd2 = bwd_ver == 2 && g.DG <= 4 && hp_bwd2_lds_bytes(gc, hd) <= 160 * 1024;
+    profile_mark(1, true, stream, bwd2 ? "hp_bwd2_kernel" : "hp_bwd_kernel");
+    if (bwd2)
       rc = hp_backward2_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                                (const int4 *)(base + L.off_tab), base + L.off_gcol,
                                (float *)(base + L.off_part), cnt, stream);
@@ -261,12 +267,15 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
     profile_mark(1, false, stream);
     if (rc) return rc;
     if ((rc = hp_reduce_grad_weight(gc, hd, dtype, (const float *)(base + L.off_part),
-                                    (const int4 *)(base + L.off_tab), t.grad_weight, stream)))
+                                    (const int4 *)(base + L.off_tab), t.grad_weight,
+                                    multi ? (float *)(base + L.off_gw32) : nullptr, first, last, stream)))
       return rc;
     if (b0 + bc >= g.B && (rc = record_weight_ready(stream))) return rc;
     if ((rc = hp_csr_build(gc, dtype, tc, cnt, rowptr, base + L.off_entries, stream))) return rc;
-    if ((rc = hp_col2im(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, stream)))
-      return rc;
+    profile_mark(3, true, stream, "hp_col2im_kernel");
+    rc = hp_col2im(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, stream);
+    profile_mark(3, false, stream);
+    if (rc) return rc;
   }
   return MDCONV_OK;
 }

@@ -17,8 +17,10 @@ int hp_pack_fwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *
                         int2 *ctab, hipStream_t stream);
 int hp_pack_bwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *w, void *wpb,
                         int4 *btab, hipStream_t stream);
+// gw32 != nullptr (calls cut into batch chunks): running fp32 sum; grad_weight is written by the last chunk
 int hp_reduce_grad_weight(const Geom &g, const HpDims &hd, int dtype, const float *part,
-                          const int4 *btab, void *grad_weight, hipStream_t stream);
+                          const int4 *btab, void *grad_weight, float *gw32, bool first, bool last,
+                          hipStream_t stream);
 int hp_grad_bias(const Geom &g, int dtype, const void *grad_output, void *grad_bias,
                  hipStream_t stream);
 

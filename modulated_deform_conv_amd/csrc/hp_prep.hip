@@ -143,7 +143,8 @@ __global__ void hp_btab_kernel(Geom g, HpDims hd, int4 *__restrict__ btab) {
 template <typename T>
 __global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, const int4 *__restrict__ btab,
                                                            const float *__restrict__ part,
-                                                           typename T::Raw *__restrict__ gw) {
+                                                           typename T::Raw *__restrict__ gw,
+                                                           float *__restrict__ gw32, int first, int last) {
   const int64_t total = (int64_t)g.K * hd.cblks * hd.MB2 * 1024;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int64_t r = i;
@@ -160,7 +161,14 @@ __global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, co
                        lane * 16 + reg;
       float s = 0.f;
       for (int k = 0; k < hd.ranges; ++k) s += p[(int64_t)k * per_range];
-      typename T::Raw *dst = gw + ((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap;
+      const int64_t e = ((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap;
+      // calls cut into batch chunks keep the running sum in fp32 (gw32) and round ONCE, after the
+      // last chunk, like the single-chunk path
+      if (gw32) {
+        if (!first) s += gw32[e];
+        if (!last) { gw32[e] = s; continue; }
+      }
+      typename T::Raw *dst = gw + e;
       T::stf(dst, g.acc_w ? T::ldf(dst) + s : s);
     }
   }
@@ -218,14 +226,15 @@ int hp_pack_bwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *
 }
 
 int hp_reduce_grad_weight(const Geom &g, const HpDims &hd, int dtype, const float *part,
-                          const int4 *btab, void *grad_weight, hipStream_t stream) {
+                          const int4 *btab, void *grad_weight, float *gw32, bool first, bool last,
+                          hipStream_t stream) {
   const int64_t total = (int64_t)g.K * hd.cblks * hd.MB2 * 1024;
   if (dtype == MDCONV_F16)
     hipLaunchKernelGGL((hp_reduce_gw_kernel<F16>), dim3(grid_for(total)), dim3(256), 0, stream, g, hd,
-                       btab, part, (_Float16 *)grad_weight);
+                       btab, part, (_Float16 *)grad_weight, gw32, first ? 1 : 0, last ? 1 : 0);
   else
     hipLaunchKernelGGL((hp_reduce_gw_kernel<BF16>), dim3(grid_for(total)), dim3(256), 0, stream, g, hd,
-                       btab, part, (__bf16 *)grad_weight);
+                       btab, part, (__bf16 *)grad_weight, gw32, first ? 1 : 0, last ? 1 : 0);
   return check_launch("hp_reduce_gw");
 }
 

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -27,8 +28,11 @@ static thread_local int g_input_layout = 0;   // MDCONV_LAYOUT_*
 // host threads (autograd runs the backward on its own worker thread), plus the most recent one per
 // device for the stream-less legacy query
 static std::mutex g_wready_mu;
-static std::map<std::pair<int, hipStream_t>, hipEvent_t> g_wready;
+struct WReady { hipEvent_t ev; unsigned long long tick; };
+static std::map<std::pair<int, hipStream_t>, WReady> g_wready;
 static std::map<int, hipEvent_t> g_wready_latest;
+static unsigned long long g_wready_tick = 0;
+constexpr size_t kWReadyMax = 64;   // streams remembered per process; least recently used are dropped
 static std::atomic<int> g_path{-1};  // -1 = not initialised from the environment yet
 
 void set_error(const char *fmt, ...) {
@@ -280,17 +284,31 @@ int record_weight_ready(hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return MDCONV_ELAUNCH;
   std::lock_guard<std::mutex> lock(g_wready_mu);
-  hipEvent_t &ev = g_wready[std::make_pair(dev, stream)];
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-    ev = nullptr;
-    set_error("hipEventCreate failed");
-    return MDCONV_ELAUNCH;
+  const auto key = std::make_pair(dev, stream);
+  auto it = g_wready.find(key);
+  if (it == g_wready.end()) {
+    if (g_wready.size() >= kWReadyMax) {   // programs that create and destroy many streams: evict the oldest
+      auto old = g_wready.begin();
+      for (auto j = g_wready.begin(); j != g_wready.end(); ++j)
+        if (j->second.tick < old->second.tick) old = j;
+      for (auto j = g_wready_latest.begin(); j != g_wready_latest.end();)
+        j = (j->second == old->second.ev) ? g_wready_latest.erase(j) : std::next(j);
+      (void)hipEventDestroy(old->second.ev);
+      g_wready.erase(old);
+    }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      set_error("hipEventCreate failed");
+      return MDCONV_ELAUNCH;
+    }
+    it = g_wready.emplace(key, WReady{ev, 0}).first;
   }
-  if (hipEventRecord(ev, stream) != hipSuccess) {
+  it->second.tick = ++g_wready_tick;
+  if (hipEventRecord(it->second.ev, stream) != hipSuccess) {
     set_error("hipEventRecord failed");
     return MDCONV_ELAUNCH;
   }
-  g_wready_latest[dev] = ev;
+  g_wready_latest[dev] = it->second.ev;
   return MDCONV_OK;
 }
 
@@ -302,7 +320,7 @@ static int wait_weight_ready(hipStream_t waiter, bool keyed, hipStream_t produce
     std::lock_guard<std::mutex> lock(g_wready_mu);
     if (keyed) {
       auto it = g_wready.find(std::make_pair(dev, producer));
-      if (it != g_wready.end()) ev = it->second;
+      if (it != g_wready.end()) ev = it->second.ev;
     } else {
       auto it = g_wready_latest.find(dev);
       if (it != g_wready_latest.end()) ev = it->second;
@@ -349,6 +367,14 @@ int mdconv_set_input_layout(int layout) {
   const int prev = g_input_layout;
   if (layout == MDCONV_LAYOUT_NCHW || layout == MDCONV_LAYOUT_CHANNELS_LAST) g_input_layout = layout;
   return prev;
+}
+
+int mdconv_input_layout_supported(const mdconv_desc *d, int layout, int backward) {
+  Geom g;
+  if (fill_geom(d, &g)) return 0;
+  if (layout == MDCONV_LAYOUT_NCHW) return 1;
+  if (layout != MDCONV_LAYOUT_CHANNELS_LAST) return 0;
+  return current_path() != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, backward != 0) && g.C % 32 == 0;
 }
 
 int mdconv_set_accumulate(int on) {

@@ -46,6 +46,16 @@ __device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); 
 __device__ __forceinline__ void st(float *p, float v) { *p = v; }
 __device__ __forceinline__ void st(double *p, double v) { *p = v; }
 __device__ __forceinline__ void st(__half *p, float v) { *p = __float2half(v); }
+// bf16 storage type of the shape-generic kernels (the native 16-bit kernels use __bf16, hp_common.hpp)
+struct bf16_t { unsigned short bits; };
+__device__ __forceinline__ float bf16_bits_to_float(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned short float_to_bf16_bits(float v) {   // round to nearest even, NaN kept quiet
+  const unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float ld(const bf16_t *p) { return bf16_bits_to_float(p->bits); }
+__device__ __forceinline__ void st(bf16_t *p, float v) { p->bits = float_to_bf16_bits(v); }
 
 // Accumulating stores (the C ABI's backward entry points accumulate, include/mdconv.h).
 __device__ __forceinline__ void atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
@@ -60,6 +70,20 @@ __device__ __forceinline__ void atomic_add(__half *p, float v) {
     unsigned short h = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
     const float f = __half2float(__ushort_as_half(h)) + v;
     const unsigned short nh = __half_as_ushort(__float2half(f));
+    const unsigned int repl = hi ? ((assumed & 0x0000ffffu) | ((unsigned int)nh << 16))
+                                 : ((assumed & 0xffff0000u) | nh);
+    old = atomicCAS(base, assumed, repl);
+  } while (old != assumed);
+}
+
+__device__ __forceinline__ void atomic_add(bf16_t *p, float v) {
+  unsigned int *base = (unsigned int *)((uintptr_t)p & ~(uintptr_t)3);
+  const bool hi = ((uintptr_t)p & 2) != 0;
+  unsigned int old = *base, assumed;
+  do {
+    assumed = old;
+    const unsigned short h = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
+    const unsigned short nh = float_to_bf16_bits(bf16_bits_to_float(h) + v);
     const unsigned int repl = hi ? ((assumed & 0x0000ffffu) | ((unsigned int)nh << 16))
                                  : ((assumed & 0xffff0000u) | nh);
     old = atomicCAS(base, assumed, repl);

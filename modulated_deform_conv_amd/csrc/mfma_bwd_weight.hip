@@ -271,7 +271,7 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
                         hipStream_t stream) {
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
   const bool padn = bd.Np != g.N;
-  profile_mark(2, true, stream);
+  profile_mark(2, true, stream, bd.cl ? "mfma_bwd_weight_cl_kernel" : "mfma_bwd_weight_kernel");
   if (bd.cl) {
     const int rcl = mfma_bwd_weight_cl_launch(g, bd, xt, ga, table, part, stream);
     if (rcl) return rcl;

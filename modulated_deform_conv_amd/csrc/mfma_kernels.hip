@@ -16,8 +16,10 @@ namespace {
 std::atomic<bool> g_prof_on{false};
 std::mutex g_prof_mu;
 struct ProfPair { hipEvent_t a, b; };
-std::vector<ProfPair> g_prof[3];
-size_t g_prof_used[3] = {0, 0, 0};
+constexpr int kProfSlots = 4;   // forward GEMM, backward data GEMM, backward weight GEMM, grad_input gather
+std::vector<ProfPair> g_prof[kProfSlots];
+size_t g_prof_used[kProfSlots] = {0, 0, 0, 0};
+const char *g_prof_name[kProfSlots] = {"", "", "", ""};
 
 // W[g*Og + o][c][tap]  ->  wp (MFMA-fragment order, mfma_tile.hpp) and wq[g][tap][o][c], zero padded.
 __global__ __launch_bounds__(256) void pack_weights_kernel(Geom g, PackDims pd,
@@ -69,9 +71,10 @@ int zero_bytes(void *p, size_t bytes, hipStream_t s) {
   return check_launch("zero");
 }
 
-void profile_mark(int which, bool begin, hipStream_t stream) {
-  if (!g_prof_on.load(std::memory_order_relaxed) || which < 0 || which > 2) return;
+void profile_mark(int which, bool begin, hipStream_t stream, const char *name) {
+  if (!g_prof_on.load(std::memory_order_relaxed) || which < 0 || which >= kProfSlots) return;
   std::lock_guard<std::mutex> lock(g_prof_mu);
+  if (name) g_prof_name[which] = name;
   if (begin) {
     if (g_prof_used[which] == g_prof[which].size()) {
       ProfPair p;
@@ -240,7 +243,7 @@ bool make_plan(const Geom &g, int dtype, bool backward, Plan *p) {
   int bc = (int)(kLim / per);
   if (bc > g.B) bc = g.B;
   p->Bc = bc;
-  p->half_io = dtype == MDCONV_F16;
+  p->half_io = dtype == MDCONV_F16 || dtype == MDCONV_BF16;
   p->gc = chunk_geom(g, bc);
   p->core_bytes = core_bytes_for(p->gc, backward);
   size_t off = p->core_bytes;
@@ -269,33 +272,74 @@ bool make_plan(const Geom &g, int dtype, bool backward, Plan *p) {
   return true;
 }
 
-__global__ __launch_bounds__(256) void widen_kernel(const __half *__restrict__ src, float *__restrict__ dst,
-                                                    int64_t n) {
+template <typename H>
+__global__ __launch_bounds__(256) void widen_kernel(const H *__restrict__ src, float *__restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    dst[i] = __half2float(src[i]);
+    dst[i] = ld(src + i);
 }
-template <bool ACCUM>
-__global__ __launch_bounds__(256) void narrow_kernel(const float *__restrict__ src, __half *__restrict__ dst,
-                                                     int64_t n) {
+template <typename H, bool ACCUM>
+__global__ __launch_bounds__(256) void narrow_kernel(const float *__restrict__ src, H *__restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    dst[i] = __float2half(ACCUM ? __half2float(dst[i]) + src[i] : src[i]);
+    st(dst + i, ACCUM ? ld(dst + i) + src[i] : src[i]);
 }
 int nblocks(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
 }
-int widen(const void *src, float *dst, int64_t n, hipStream_t s) {
+// 16-bit tensors the native kernels do not take (hp_supported) run through fp32 copies: fp16 and bf16
+int widen(int dtype, const void *src, float *dst, int64_t n, hipStream_t s) {
   if (n == 0) return MDCONV_OK;
-  hipLaunchKernelGGL(widen_kernel, dim3(nblocks(n)), dim3(256), 0, s, (const __half *)src, dst, n);
+  if (dtype == MDCONV_BF16)
+    hipLaunchKernelGGL(widen_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, s, (const bf16_t *)src, dst, n);
+  else
+    hipLaunchKernelGGL(widen_kernel<__half>, dim3(nblocks(n)), dim3(256), 0, s, (const __half *)src, dst, n);
   return check_launch("widen");
 }
-int narrow(const float *src, void *dst, int64_t n, bool accum, hipStream_t s) {
-  if (n == 0) return MDCONV_OK;
+template <typename H> void narrow_t(const float *src, void *dst, int64_t n, bool accum, hipStream_t s) {
   if (accum)
-    hipLaunchKernelGGL(narrow_kernel<true>, dim3(nblocks(n)), dim3(256), 0, s, src, (__half *)dst, n);
+    hipLaunchKernelGGL((narrow_kernel<H, true>), dim3(nblocks(n)), dim3(256), 0, s, src, (H *)dst, n);
   else
-    hipLaunchKernelGGL(narrow_kernel<false>, dim3(nblocks(n)), dim3(256), 0, s, src, (__half *)dst, n);
+    hipLaunchKernelGGL((narrow_kernel<H, false>), dim3(nblocks(n)), dim3(256), 0, s, src, (H *)dst, n);
+}
+int narrow(int dtype, const float *src, void *dst, int64_t n, bool accum, hipStream_t s) {
+  if (n == 0) return MDCONV_OK;
+  if (dtype == MDCONV_BF16) narrow_t<bf16_t>(src, dst, n, accum, s);
+  else narrow_t<__half>(src, dst, n, accum, s);
   return check_launch("narrow");
+}
+
+// Fork / join helper for the one piece of the backward that does not depend on its neighbour: the
+// grad_input gather (CSR build + col2im, HBM-bound) needs GEMM-1's grad_col and counters only, GEMM-2
+// (matrix-bound) needs GEMM-1's packed grad_out and tap table only.  One side stream and two events
+// per (device, caller stream), created on first use and kept (bounded like the weights-ready events).
+struct Fork { hipStream_t side; hipEvent_t fork, join; };
+std::mutex g_fork_mu;
+std::vector<std::pair<std::pair<int, hipStream_t>, Fork>> g_forks;
+bool get_fork(hipStream_t stream, Fork *out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(g_fork_mu);
+  for (auto &e : g_forks)
+    if (e.first.first == dev && e.first.second == stream) { *out = e.second; return true; }
+  if (g_forks.size() >= 64) {
+    (void)hipEventDestroy(g_forks.front().second.fork);
+    (void)hipEventDestroy(g_forks.front().second.join);
+    (void)hipStreamDestroy(g_forks.front().second.side);
+    g_forks.erase(g_forks.begin());
+  }
+  Fork f;
+  if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) return false;
+  if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess)
+    return false;
+  g_forks.push_back({{dev, stream}, f});
+  *out = f;
+  return true;
+}
+// MDCONV_BWD_FORK = 0 / 1: run the grad_input gather beside GEMM-2 on a forked stream (read once)
+bool bwd_fork_enabled() {
+  static const int on = getenv("MDCONV_BWD_FORK") ? atoi(getenv("MDCONV_BWD_FORK")) : 0;
+  return on != 0;
 }
 
 // fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`).
@@ -327,20 +371,43 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   // channels-last copy of the input for the 3-D gathers of GEMM-1's drain and of GEMM-2
   float *xt = bd.cl ? (float *)(base + bd.off_xt) : nullptr;
   if (bd.cl && (rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream))) return rc;
-  profile_mark(1, true, stream);
+  profile_mark(1, true, stream, "mfma_bwd_data_kernel");
   rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, stream);
   profile_mark(1, false, stream);
   if (rc) return rc;
-  if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
-  if (weights_final && (rc = record_weight_ready(stream))) return rc;
-  if ((rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, stream))) return rc;
-  return col2im_f32(g, bd, t, gcol, rowptr, entries, stream);
+  Fork fk;
+  const bool fork = bwd_fork_enabled() && get_fork(stream, &fk);
+  hipStream_t gs = stream;   // stream of the grad_input gather
+  if (fork) {
+    if (hipEventRecord(fk.fork, stream) != hipSuccess || hipStreamWaitEvent(fk.side, fk.fork, 0) != hipSuccess) {
+      set_error("backward fork failed");
+      return MDCONV_ELAUNCH;
+    }
+    gs = fk.side;
+  } else {
+    if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
+    if (weights_final && (rc = record_weight_ready(stream))) return rc;
+  }
+  if ((rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, gs))) return rc;
+  profile_mark(3, true, gs, bd.sample_keyed ? "col2im3d_kernel" : "col2im_gather_kernel");
+  rc = col2im_f32(g, bd, t, gcol, rowptr, entries, gs);
+  profile_mark(3, false, gs);
+  if (rc) return rc;
+  if (fork) {
+    if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
+    if (weights_final && (rc = record_weight_ready(stream))) return rc;
+    if (hipEventRecord(fk.join, fk.side) != hipSuccess || hipStreamWaitEvent(stream, fk.join, 0) != hipSuccess) {
+      set_error("backward join failed");
+      return MDCONV_ELAUNCH;
+    }
+  }
+  return MDCONV_OK;
 }
 
 }  // namespace
 
 bool mfma_supported(const Geom &g, int dtype, bool backward) {
-  if (dtype != MDCONV_F32 && dtype != MDCONV_F16) return false;
+  if (dtype != MDCONV_F32 && dtype != MDCONV_F16 && dtype != MDCONV_BF16) return false;
   if (g.in_sz[g.nd - 1] < 2) return false;   // paired-corner gathers need 2 columns
   if (!backward) {
     if (g.Cg < 16 || g.Og < 16) return false;  // MFMA tiles would be mostly padding
@@ -371,8 +438,8 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
   int rc;
   const float *w32 = (const float *)t.weight, *b32 = (const float *)t.bias;
   if (p.half_io) {
-    if ((rc = widen(t.weight, (float *)(base + p.off_w), (int64_t)g.O * g.Cg * g.K, stream))) return rc;
-    if (g.with_bias && (rc = widen(t.bias, (float *)(base + p.off_b), g.O, stream))) return rc;
+    if ((rc = widen(dtype, t.weight, (float *)(base + p.off_w), (int64_t)g.O * g.Cg * g.K, stream))) return rc;
+    if (g.with_bias && (rc = widen(dtype, t.bias, (float *)(base + p.off_b), g.O, stream))) return rc;
     w32 = (const float *)(base + p.off_w);
     b32 = (const float *)(base + p.off_b);
   }
@@ -390,9 +457,9 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
     tc.weight = w32;
     tc.bias = b32;
     if (p.half_io) {
-      if ((rc = widen(x, (float *)(base + p.off_x), (int64_t)bc * g.C * g.S_i, stream))) return rc;
-      if ((rc = widen(of, (float *)(base + p.off_off), (int64_t)bc * nc_off * g.S_o, stream))) return rc;
-      if (mk && (rc = widen(mk, (float *)(base + p.off_m), (int64_t)bc * nc_m * g.S_o, stream))) return rc;
+      if ((rc = widen(dtype, x, (float *)(base + p.off_x), (int64_t)bc * g.C * g.S_i, stream))) return rc;
+      if ((rc = widen(dtype, of, (float *)(base + p.off_off), (int64_t)bc * nc_off * g.S_o, stream))) return rc;
+      if (mk && (rc = widen(dtype, mk, (float *)(base + p.off_m), (int64_t)bc * nc_m * g.S_o, stream))) return rc;
       tc.input = base + p.off_x;
       tc.offset = base + p.off_off;
       tc.mask = mk ? base + p.off_m : nullptr;
@@ -400,7 +467,7 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
     } else {
       tc.input = x; tc.offset = of; tc.mask = mk; tc.output = out;
     }
-    profile_mark(0, true, stream);
+    profile_mark(0, true, stream, fwd_channels_last(gc) ? "mfma_fwd_cl_kernel" : "mfma_fwd_kernel");
     if (fwd_channels_last(gc)) {
       float *xt = (float *)(base + align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float)));
       rc = mfma_forward_cl_f32(gc, pd, tc, wp, xt, stream);
@@ -409,7 +476,7 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
     }
     profile_mark(0, false, stream);
     if (rc) return rc;
-    if (p.half_io && (rc = narrow((const float *)tc.output, out, (int64_t)bc * g.O * g.S_o, false, stream)))
+    if (p.half_io && (rc = narrow(dtype, (const float *)tc.output, out, (int64_t)bc * g.O * g.S_o, false, stream)))
       return rc;
   }
   return MDCONV_OK;
@@ -424,7 +491,7 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
   const int64_t n_w = (int64_t)g.O * g.Cg * g.K;
   int rc;
   if (p.half_io) {
-    if ((rc = widen(t.weight, (float *)(base + p.off_w), n_w, stream))) return rc;
+    if ((rc = widen(dtype, t.weight, (float *)(base + p.off_w), n_w, stream))) return rc;
   }
   for (int b0 = 0; b0 < g.B; b0 += p.Bc) {
     const int bc = g.B - b0 < p.Bc ? g.B - b0 : p.Bc;
@@ -440,20 +507,20 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
     if (p.half_io) {
       const int64_t n_x = (int64_t)bc * g.C * g.S_i, n_off = (int64_t)bc * nc_off * g.S_o;
       const int64_t n_m = (int64_t)bc * nc_m * g.S_o, n_go = (int64_t)bc * g.O * g.S_o;
-      if ((rc = widen((const char *)t.input + o_x * es, (float *)(base + p.off_x), n_x, stream))) return rc;
-      if ((rc = widen((const char *)t.offset + o_off * es, (float *)(base + p.off_off), n_off, stream))) return rc;
-      if (t.mask && (rc = widen((const char *)t.mask + o_m * es, (float *)(base + p.off_m), n_m, stream))) return rc;
-      if ((rc = widen((const char *)t.grad_output + o_go * es, (float *)(base + p.off_go), n_go, stream))) return rc;
+      if ((rc = widen(dtype, (const char *)t.input + o_x * es, (float *)(base + p.off_x), n_x, stream))) return rc;
+      if ((rc = widen(dtype, (const char *)t.offset + o_off * es, (float *)(base + p.off_off), n_off, stream))) return rc;
+      if (t.mask && (rc = widen(dtype, (const char *)t.mask + o_m * es, (float *)(base + p.off_m), n_m, stream))) return rc;
+      if ((rc = widen(dtype, (const char *)t.grad_output + o_go * es, (float *)(base + p.off_go), n_go, stream))) return rc;
       tc.input = base + p.off_x; tc.offset = base + p.off_off; tc.mask = t.mask ? base + p.off_m : nullptr;
       tc.weight = base + p.off_w; tc.grad_output = base + p.off_go;
       tc.grad_input = base + p.off_gi; tc.grad_offset = base + p.off_goff;
       tc.grad_mask = t.grad_mask ? base + p.off_gm : nullptr;
       tc.grad_weight = base + p.off_gw; tc.grad_bias = base + p.off_gb;
       if ((rc = backward_chunk_f32(gc, tc, base, stream, false))) return rc;
-      if ((rc = narrow((const float *)tc.grad_input, (char *)t.grad_input + o_x * es, n_x, g.acc_data != 0, stream))) return rc;
-      if ((rc = narrow((const float *)tc.grad_offset, (char *)t.grad_offset + o_off * es, n_off, g.acc_data != 0, stream))) return rc;
+      if ((rc = narrow(dtype, (const float *)tc.grad_input, (char *)t.grad_input + o_x * es, n_x, g.acc_data != 0, stream))) return rc;
+      if ((rc = narrow(dtype, (const float *)tc.grad_offset, (char *)t.grad_offset + o_off * es, n_off, g.acc_data != 0, stream))) return rc;
       if (t.grad_mask &&
-          (rc = narrow((const float *)tc.grad_mask, (char *)t.grad_mask + o_m * es, n_m, g.acc_data != 0, stream)))
+          (rc = narrow(dtype, (const float *)tc.grad_mask, (char *)t.grad_mask + o_m * es, n_m, g.acc_data != 0, stream)))
         return rc;
     } else {
       tc.input = (const char *)t.input + o_x * es;
@@ -467,8 +534,8 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
     }
   }
   if (p.half_io) {
-    if ((rc = narrow((const float *)(base + p.off_gw), t.grad_weight, n_w, g.acc_w != 0, stream))) return rc;
-    if (g.with_bias && (rc = narrow((const float *)(base + p.off_gb), t.grad_bias, g.O, g.acc_w != 0, stream))) return rc;
+    if ((rc = narrow(dtype, (const float *)(base + p.off_gw), t.grad_weight, n_w, g.acc_w != 0, stream))) return rc;
+    if (g.with_bias && (rc = narrow(dtype, (const float *)(base + p.off_gb), t.grad_bias, g.O, g.acc_w != 0, stream))) return rc;
     if ((rc = record_weight_ready(stream))) return rc;
   }
   return MDCONV_OK;
@@ -483,10 +550,15 @@ int mdconv_profile_enable(int on) {
 }
 void mdconv_profile_reset(void) {
   std::lock_guard<std::mutex> lock(mdconv::g_prof_mu);
-  for (int i = 0; i < 3; ++i) mdconv::g_prof_used[i] = 0;
+  for (int i = 0; i < mdconv::kProfSlots; ++i) mdconv::g_prof_used[i] = 0;
+}
+const char *mdconv_profile_name(int which) {
+  if (which < 0 || which >= mdconv::kProfSlots) return "";
+  std::lock_guard<std::mutex> lock(mdconv::g_prof_mu);
+  return mdconv::g_prof_name[which];
 }
 int mdconv_profile_read(int which, double *total_ms) {
-  if (which < 0 || which > 2) return 0;
+  if (which < 0 || which >= mdconv::kProfSlots) return 0;
   double tot = 0;
   int n = 0;
   std::lock_guard<std::mutex> lock(mdconv::g_prof_mu);

@@ -17,6 +17,6 @@ int record_weight_ready(hipStream_t stream);
 int zero_bytes(void *p, size_t bytes, hipStream_t stream);
 
 // benchmark hooks (include/mdconv.h: mdconv_profile_*)
-void profile_mark(int which, bool begin, hipStream_t stream);
+void profile_mark(int which, bool begin, hipStream_t stream, const char *name = nullptr);
 
 }  // namespace mdconv

@@ -1,5 +1,6 @@
-"""Full-shape oracle checks at BASELINE.json configs[2..4] (per-GPU shards):
+"""Full-shape oracle checks at BASELINE.json configs[1..4] (per-GPU shards):
 
+  cfg2  ModulatedDeformConv2d C=256 56x56 B=32 fp32 (the headline configuration of bench.py)
   cfg3  ModulatedDeformConv2d C=256 56x56 B=32 group=32 deformable_group=4 fp16
   cfg4  DeformConv3d 3x3x3 C=64 32^3 B=8 fp32
   cfg5  ModulatedDeformConv3d C=128 16x64x64 B=8 dilation=2 fp16 (the >2 GiB grad_col path)
@@ -10,7 +11,7 @@ only (mdeformable_conv.cu:54, 64-66, 228), so image 0 and the last image are com
 oracle run on those one-image slices.  grad_weight / grad_bias sum over the batch
 (mdeformable_conv.cu:436-444): they are checked on the first two images (product B=2 vs oracle
 B=2) and, at full size, by additivity over the two half shards.
-Tolerances: 1e-4 fp32, 2e-2 fp16 (fp32 oracle on the fp16-rounded inputs), both criteria of
+Tolerances: 1e-4 fp32, 5e-3 fp16 (fp32 oracle on the fp16-rounded inputs), both criteria of
 tests.util.assert_close.
 """
 import math
@@ -95,8 +96,12 @@ def _check_config(op, B, C, O, sp, nd, modulated, groups, dgroups, dtype, pad, d
     assert_close("grad_weight additivity", parts[0] + parts[1], full["grad_weight"].float(), tol)
 
 
+def test_cfg2_full_shard_vs_oracle():
+    _check_config(oracle.MDCN2D, 32, 256, 256, (56, 56), 2, True, 1, 1, torch.float32, 1, 1, 1e-4, 2, "f32")
+
+
 def test_cfg3_full_shard_vs_oracle():
-    _check_config(oracle.MDCN2D, 32, 256, 256, (56, 56), 2, True, 32, 4, torch.float16, 1, 1, 2e-2, 3, "hp")
+    _check_config(oracle.MDCN2D, 32, 256, 256, (56, 56), 2, True, 32, 4, torch.float16, 1, 1, 5e-3, 3, "hp")
 
 
 def test_cfg4_full_shard_vs_oracle():
@@ -104,4 +109,4 @@ def test_cfg4_full_shard_vs_oracle():
 
 
 def test_cfg5_full_shard_vs_oracle():
-    _check_config(oracle.MDCN3D, 8, 128, 128, (16, 64, 64), 3, True, 1, 1, torch.float16, 2, 2, 2e-2, 5, "hp")
+    _check_config(oracle.MDCN3D, 8, 128, 128, (16, 64, 64), 3, True, 1, 1, torch.float16, 2, 2, 5e-3, 5, "hp")

@@ -3,8 +3,8 @@ v_mfma_f32_32x32x16_{f16,bf16}, fp32 coordinates / weights / accumulators) again
 run on the same 16-bit-rounded inputs.  Reference dtype dispatch: mdeformable_conv.cu:101, 334
 (AT_DISPATCH_FLOATING_TYPES_AND_HALF); bf16 is the SURVEY.md section 8f-3 extension.
 
-Tolerance: 2e-2 (fp16) / 6e-2 (bf16) on both criteria of tests.util.assert_close -- the outputs
-themselves are rounded to 11 / 8 significant bits.
+Tolerance: 5e-3 (fp16) / 3e-2 (bf16) on both criteria of tests.util.assert_close -- the outputs
+themselves are rounded to 11 / 8 significant bits (measured worst case 1.9e-3 / 1.4e-2).
 """
 import pytest
 import torch
@@ -14,7 +14,7 @@ from tests.util import assert_close, run_oracle, run_product
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float16: 2e-2, torch.bfloat16: 6e-2}
+TOL = {torch.float16: 5e-3, torch.bfloat16: 3e-2}
 
 # shapes written for this path: channel counts around the 32-channel blocks, conv groups that
 # share a block (cfg3: 8 channels per group), deformable groups of 32 / 64 channels, C_out spans
@@ -35,6 +35,20 @@ HP_CASES = [
     _c("hp_mdcn3d_c64_g2_dg2", M3, 1, 64, 64, (4, 5, 6), 3, groups=2, dgroups=2, seed=114),
     _c("hp_mdcn2d_c256_o256", M2, 1, 256, 256, (8, 8), 3, seed=115),
     _c("hp_mdcn2d_pixels_not_mult8", M2, 3, 32, 32, (7, 7), 3, seed=116),
+    # more than 4 deformable groups: beyond the (pixel, deformable group) state table of the
+    # line-wide backward, i.e. the lane = pixel kernel (hp_bwd.hip) is what runs
+    _c("hp_mdcn2d_c256_o64_dg8", M2, 2, 256, 64, (9, 8), 3, dgroups=8, seed=117),
+    _c("hp_dcn3d_c256_o32_dg8", D3, 1, 256, 32, (4, 5, 6), 3, dgroups=8, bias=False, seed=118),
+]
+
+# 16-bit shapes the native kernels reject in at least one direction (hp_supported): more than 256
+# input channels / a block's output range above 256 in the backward, deformable groups of 16
+# channels.  fp16 AND bf16 must still work (fp32 copies through the fp32 kernels, else the
+# shape-generic kernels) -- ADVICE round 2: bf16 used to end in "unknown dtype 3".
+FALLBACK_CASES = [
+    _c("fb_mdcn2d_c512_o64", M2, 1, 512, 64, (7, 6), 3, seed=131),
+    _c("fb_mdcn2d_c64_o64_dg4", M2, 2, 64, 64, (8, 7), 3, dgroups=4, seed=132),
+    _c("fb_dcn3d_c24_o8_g2", D3, 1, 24, 8, (4, 5, 4), 3, groups=2, bias=False, seed=133),
 ]
 
 
@@ -62,6 +76,58 @@ def test_hp_fp16(case):
 @pytest.mark.parametrize("case", HP_CASES[::2], ids=lambda c: c["name"])
 def test_hp_bf16(case):
     _check(case, torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("case", FALLBACK_CASES, ids=lambda c: c["name"])
+def test_16bit_shapes_outside_the_native_kernels(case, dtype):
+    _check(case, dtype, expect_hp=False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_autocast_on_a_shape_the_native_backward_rejects(dtype):
+    """torch.autocast on a C_in = 512 layer: the forward qualifies for the native 16-bit kernels,
+    the backward does not (more than 8 channel blocks) -- loss.backward() must still work."""
+    from modulated_deform_conv_amd.modulated_deform_conv import ModulatedDeformConv2d
+    case = FALLBACK_CASES[0]
+    t = make_inputs(case, dtype=torch.float32, device="cuda")
+    mod = ModulatedDeformConv2d(512, 64, 3, padding=1, bias=True).cuda()
+    with torch.no_grad():
+        mod.weight.copy_(t["weight"]); mod.bias.copy_(t["bias"])
+    x, off, m = (t[k].clone().requires_grad_() for k in ("input", "offset", "mask"))
+    with torch.autocast("cuda", dtype=dtype):
+        out = mod(x, off, m)
+    assert out.dtype == dtype
+    out.backward(t["grad_output"].to(dtype))
+    r = lambda v: v.to(dtype).float()
+    want_out, want = run_oracle(case, {k: (None if v is None else r(v)) for k, v in t.items()}, torch.float32)
+    tol = TOL[dtype]
+    assert_close("output", out.float(), want_out, tol)
+    assert x.grad.dtype == torch.float32 and mod.weight.grad.dtype == torch.float32
+    assert_close("grad_input", x.grad, want["grad_input"], tol)
+    assert_close("grad_offset", off.grad, want["grad_offset"], tol)
+    assert_close("grad_mask", m.grad, want["grad_mask"], tol)
+    assert_close("grad_weight", mod.weight.grad, want["grad_weight"], tol)
+    assert_close("grad_bias", mod.bias.grad, want["grad_bias"], tol)
+
+
+def test_channels_last_input_on_a_shape_the_native_backward_rejects():
+    """A channels_last fp16 input with C_in = 512: consumed in place by the forward, and the
+    backward of the same autograd Function (which saved the channels-last tensor) falls back to a
+    contiguous copy instead of raising."""
+    from modulated_deform_conv_amd.modulated_deform_conv import modulated_deform_conv2d
+    case = FALLBACK_CASES[0]
+    t = make_inputs(case, dtype=torch.float16, device="cuda")
+    res = []
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        x = t["input"].contiguous(memory_format=fmt).requires_grad_()
+        off, m, w = (t[k].clone().requires_grad_() for k in ("offset", "mask", "weight"))
+        out = modulated_deform_conv2d(x, off, m, w, t["bias"], 1, 1, 1, 1, 1, 64)
+        out.backward(t["grad_output"])
+        res.append((out, x.grad, off.grad, m.grad, w.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b, name in zip(res[0][1:], res[1][1:], ("grad_input", "grad_offset", "grad_mask", "grad_weight")):
+        assert_close(name, b.float(), a.float(), 2e-3, 1e-2)
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["tier"] == "medium"], ids=lambda c: c["name"])

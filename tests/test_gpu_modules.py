@@ -128,7 +128,7 @@ def test_autocast_runs_on_the_native_16bit_kernels(dt):
     with torch.autocast("cuda", dtype=dt):
         y = m(x, off.half(), mask)        # mixed input dtypes are fine under autocast
     assert y.dtype == dt and _capi.last_kernels() == "hp"
-    assert_close("autocast", y.float(), ref, 2e-2 if dt == torch.float16 else 6e-2)
+    assert_close("autocast", y.float(), ref, 2e-2 if dt == torch.float16 else 6e-2)   # inputs are rounded to 16 bits here and not in `ref`: not an oracle-parity tolerance
     y.float().sum().backward()
     assert x.grad is not None and x.grad.dtype == torch.float32 and torch.isfinite(x.grad).all()
     assert m.weight.grad.dtype == torch.float32
@@ -232,3 +232,63 @@ def test_hip_graph_capture_and_replay(name):
     for k, v in g.items():
         if v is not None and ref_g[k] is not None:
             assert_close(k, v, ref_g[k], 1e-5)
+
+
+@pytest.mark.parametrize("cls_name, nd, modulated, kw", [
+    ("ModulatedDeformConv2dPack", 2, True, dict(stride=2, deformable_groups=2)),
+    ("DeformConv2dPack", 2, False, dict(groups=2)),
+    ("ModulatedDeformConv3dPack", 3, True, dict()),
+    ("DeformConv3dPack", 3, False, dict(deformable_groups=2)),
+])
+def test_pack_module_matches_oracle(cls_name, nd, modulated, kw):
+    """*Pack modules against the ORACLE (reference modulated_deform_conv.py:730-839): offset (and
+    mask) are what the side convolutions produce -- same kernel / stride / padding as the main
+    convolution, dilation NOT forwarded, no sigmoid on the mask (the reference's quirks) -- and the
+    oracle runs the deformable convolution on them; the gradients of x and of the side convolutions'
+    parameters are chained through F.conv on the CPU."""
+    import oracle
+    from modulated_deform_conv_amd import modulated_deform_conv as mdc
+    torch.manual_seed(7)
+    C, O, B = 16, 24, 2
+    sp = (10, 9) if nd == 2 else (5, 6, 5)
+    stride, groups, dg = kw.get("stride", 1), kw.get("groups", 1), kw.get("deformable_groups", 1)
+    mod = getattr(mdc, cls_name)(C, O, 3, stride=stride, padding=1, groups=groups,
+                                 deformable_groups=dg, bias=True).cuda()
+    with torch.no_grad():
+        mod.bias.normal_(0, 0.1)
+        mod.conv_offset.bias.normal_(0, 0.3)       # the reference initialises these to 0; make them count
+        mod.conv_offset.weight.mul_(6.0)           # offsets of about a pixel
+        if modulated:
+            mod.conv_mask.bias.normal_(0.5, 0.2)
+    x = torch.randn(B, C, *sp, device="cuda", requires_grad=True)
+    out = mod(x)
+    go = torch.randn_like(out)
+    out.backward(go)
+    # expected: side convolutions on the CPU (autograd), deformable convolution by the oracle
+    conv = F.conv2d if nd == 2 else F.conv3d
+    xc = x.detach().cpu().requires_grad_()
+    cw = mod.conv_offset.weight.detach().cpu().requires_grad_()
+    cb = mod.conv_offset.bias.detach().cpu().requires_grad_()
+    off = conv(xc, cw, cb, stride, 1)              # dilation not forwarded
+    if modulated:
+        mw = mod.conv_mask.weight.detach().cpu().requires_grad_()
+        mb = mod.conv_mask.bias.detach().cpu().requires_grad_()
+        mask = conv(xc, mw, mb, stride, 1)         # no sigmoid
+    op = {(2, False): oracle.DCN2D, (2, True): oracle.MDCN2D, (3, False): oracle.DCN3D, (3, True): oracle.MDCN3D}[(nd, modulated)]
+    w, b = mod.weight.detach().cpu(), mod.bias.detach().cpu()
+    md = mask.detach() if modulated else None
+    want_out = oracle.forward(op, xc.detach(), w, b, off.detach(), md, stride, 1, 1, groups, dg, 64, dtype=torch.float32)
+    g = oracle.backward(op, xc.detach(), w, b, off.detach(), md, go.cpu(), stride, 1, 1, groups, dg, 64, dtype=torch.float32)
+    heads, grads = [off], [g["grad_offset"]]
+    if modulated:
+        heads.append(mask); grads.append(g["grad_mask"])
+    torch.autograd.backward(heads, grads)
+    assert_close("output", out, want_out, 1e-4)
+    assert_close("x.grad", x.grad, g["grad_input"] + xc.grad, 1e-4)
+    assert_close("weight.grad", mod.weight.grad, g["grad_weight"], 1e-4)
+    assert_close("bias.grad", mod.bias.grad, g["grad_bias"], 1e-4)
+    assert_close("conv_offset.weight.grad", mod.conv_offset.weight.grad, cw.grad, 1e-4)
+    assert_close("conv_offset.bias.grad", mod.conv_offset.bias.grad, cb.grad, 1e-4)
+    if modulated:
+        assert_close("conv_mask.weight.grad", mod.conv_mask.weight.grad, mw.grad, 1e-4)
+        assert_close("conv_mask.bias.grad", mod.conv_mask.bias.grad, mb.grad, 1e-4)

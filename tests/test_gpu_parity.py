@@ -3,18 +3,18 @@ C ABI -> kernels), against the CPU oracle on the same seeded inputs.
 
 Tolerance (BASELINE.json north_star: "within 1e-4 fp32"), read relative to scale as SURVEY.md
 section 8c prescribes:  max|got - want| <= 1e-4 * max(1, max|want|)   for fp32,
-1e-10 for fp64, and 2e-2 for fp16 storage (fp32 arithmetic inside; compared with the fp32 oracle
+1e-10 for fp64, and 5e-3 for fp16 storage (fp32 arithmetic inside; compared with the fp32 oracle
 run on the fp16-rounded inputs).
 """
 import pytest
 import torch
 
-from tests.cases import CASES, make_inputs
+from tests.cases import CASES, CASE_BY_NAME, make_inputs
 from tests.util import assert_close, run_oracle, run_product
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 1e-4, torch.float64: 1e-10, torch.float16: 2e-2}
+TOL = {torch.float32: 1e-4, torch.float64: 1e-10, torch.float16: 5e-3}
 
 
 def _check(case, dtype, path):
@@ -126,7 +126,7 @@ sys.path.insert(0, %r)
 from tests.cases import CASE_BY_NAME, make_inputs
 from tests.util import run_product, run_oracle, assert_close
 from modulated_deform_conv_amd import _capi
-for name, dt, tol in (("cfg2s_mdcn2d_c64_28x28_b4", torch.float32, 1e-4), ("cfg2s_mdcn2d_c64_28x28_b4", torch.float16, 2e-2),
+for name, dt, tol in (("cfg2s_mdcn2d_c64_28x28_b4", torch.float32, 1e-4), ("cfg2s_mdcn2d_c64_28x28_b4", torch.float16, 5e-3),
                       ("cfg4s_dcn3d_c16_12cubed_b2", torch.float32, 1e-4)):
     case = CASE_BY_NAME[name]
     t = make_inputs(case, dtype=dt, device="cuda")
@@ -189,3 +189,21 @@ def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
             continue
         assert torch.isfinite(g).all(), key
         assert_close(key, g, want[key], tol, elem_tol)
+
+
+@pytest.mark.parametrize("path", ["mfma", "direct"])
+@pytest.mark.xfail(strict=True, reason="documented deviation (INTEGRATION.md, Limits): the fp32 kernels fetch "
+                   "corner PAIRS with one load and fold validity into the weights, so the neighbour of an "
+                   "out-of-image corner is read with weight 0 and 0 * Inf = NaN, where the reference never "
+                   "reads it (mdeformable_conv.cu:9-34); masking the values costs a VALU select per loaded "
+                   "element inside the MFMA-bound K loops")
+def test_fp32_non_finite_border_pixel_is_not_read(path):
+    """The 16-bit twin of this test (tests/test_gpu_hp.py) passes: those kernels park invalid
+    corners out of the buffer's range."""
+    case = CASE_BY_NAME["mfma_mdcn2d_c32_o48_9x10"]
+    t = make_inputs(case, dtype=torch.float32, device="cuda")
+    t["offset"].zero_()
+    t["input"][0, :, 0, 1] = float("inf")     # reached as the unused pair element of column -1 / 0 samples
+    out, _, _ = run_product(case, t, path)
+    want_out, _ = run_oracle(case, t, torch.float32)
+    assert torch.equal(torch.isfinite(out.cpu()), torch.isfinite(want_out))
