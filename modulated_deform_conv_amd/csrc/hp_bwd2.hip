@@ -100,12 +100,13 @@ template <int ND> __device__ __forceinline__ void advance_pixel(const Geom &g, i
 // pipeline -- offsets / mask, sampling state, CSR counting, the final grad_offset / grad_mask
 // arithmetic -- beside them (it was 47 % of the tile time when wave 0 did it on top of its share).
 template <int ND, bool MOD, typename T, int WAVES, int NKS, int NS>
-__global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2_kernel(
+__global__ __launch_bounds__(64 * (WAVES + NS), kHpFuse2 ? (WAVES >= 8 ? 1 : 2) : ((WAVES >= 8 || NKS >= 16) ? 2 : 3)) void hp_bwd2_kernel(
     Geom g, HpDims hd, const typename T::Raw *__restrict__ xt, const U4 *__restrict__ wpb,
     const int4 *__restrict__ btab, const typename T::Raw *__restrict__ gout,
     const typename T::Raw *__restrict__ offset, const typename T::Raw *__restrict__ mask,
-    typename T::Raw *__restrict__ gcol, typename T::Raw *__restrict__ grad_offset,
-    typename T::Raw *__restrict__ grad_mask, float *__restrict__ part, int *__restrict__ cnt) {
+    typename T::Raw *__restrict__ gcol, typename T::Raw *__restrict__ colbuf,
+    typename T::Raw *__restrict__ grad_offset, typename T::Raw *__restrict__ grad_mask,
+    float *__restrict__ part, int *__restrict__ cnt) {
   using Raw = typename T::Raw;
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB2 = NKS / 2;
@@ -117,8 +118,8 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
   const int pitch_gc = Cp + 8;
   Raw *Gop = reinterpret_cast<Raw *>(smem);            // [2][OpL][kPP]   grad_out tile, [o][pixel]
   Raw *Gc = Gop + 2 * OpL * kPP;                       // [32][pitch_gc]  grad_col tile, [pixel][c]
-  Raw *Col = Gc + 32 * pitch_gc;                       // [32][pitch_gc]  column tile,   [pixel][c]
-  int *St = reinterpret_cast<int *>(Col + 32 * pitch_gc);              // [2][32 * DG][SW]
+  Raw *Col = Gc + 32 * pitch_gc;                       // [32][pitch_gc]  column tile,   [pixel][c] (fused GEMM-2 only)
+  int *St = reinterpret_cast<int *>(Col + (kHpFuse2 ? 32 * pitch_gc : 0));   // [2][32 * DG][SW]
   float *Spart = reinterpret_cast<float *>(St + 2 * 32 * g.DG * SW);   // [32 * DG][msub][NC]
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, pl = lane & 31;
@@ -323,11 +324,13 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
   for (int ks = 0; ks < NKS; ++ks)
     wf[ks] = active ? wpb[(((int64_t)tap * hd.cblks + cblk) * NKS + ks) * 64 + lane] : U4{0, 0, 0, 0};
 
-  f32x16 acc2[MB2];
+  f32x16 acc2[kHpFuse2 ? MB2 : 1];
+  if (kHpFuse2) {
 #pragma unroll
-  for (int i = 0; i < MB2; ++i)
+    for (int i = 0; i < MB2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+  }
 
   // ---- grad_out tile: item = (o, pixel octet); two items per thread in flight, tail loop.
   // (gb, gp) = image / pixel of the first pixel of the NEXT tile to load (wave-uniform) ----
@@ -429,6 +432,7 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
       int grow[NI], gimg[NI];
       const int *st_tile = St + buf * 32 * g.DG * SW;
       const rsrc_t r_gcol = make_rsrc(gcol + (size_t)cb * gcol_img, gcol_img * 2);   // image of this tile (tile_ok)
+      const rsrc_t r_col = make_rsrc(colbuf + (size_t)cb * gcol_img, gcol_img * 2);
       auto request = [&](int k, int slot) {
         if (it_on[k]) {
           const int *sp = st_tile + (it_p[k] * g.DG + it_dg[k]) * SW;
@@ -462,7 +466,12 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
             S[ci] = dot8<T>(0.f, x[slot][ci], gq[slot]);
             mac8<T>(col, x[slot][ci], wm[slot][ci]);
           }
-          *reinterpret_cast<U4 *>(Col + it_p[k] * pitch_gc + it_oc[k] * 8) = pack8<T>(col);
+          if (kHpFuse2)
+            *reinterpret_cast<U4 *>(Col + it_p[k] * pitch_gc + it_oc[k] * 8) = pack8<T>(col);
+          else if (tile_ok)   // column row (addressed like the grad_col row) for the dense GEMM-2 kernel
+            buf_store4u(r_col, grow[slot] + it_oc[k] * 16, 0, pack8<T>(col));
+          else if (grow[slot] != kHpOob)
+            *reinterpret_cast<U4 *>(colbuf + (size_t)gimg[slot] * gcol_img + (grow[slot] >> 1) + it_oc[k] * 8) = pack8<T>(col);
           // reduce S over the `sub` lanes that share (pixel, dg); partials -> LDS.  Up to 16 lanes
           // (one DPP row) with DPP operands, ds_bpermute only beyond
           hp_dpp_sum<NC>(S, sub);
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
     HP_T(5);
     // ================= P4: GEMM-2 =================
     if (tile + 2 < t_hi) { g_load(); g_advance(); }
-    if (active) {
+    if (kHpFuse2 && active) {
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
         // B fragment (K = pixel, N = channel) from the [pixel][c] column tile
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
   if (lane == 0 && wave < 2)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_hp_timing[wave * 8 + i], t_acc[i]);
 #endif
-  if (active) {
+  if (kHpFuse2 && active) {
     float4 *dst = reinterpret_cast<float4 *>(
         part + ((((int64_t)tap * hd.ranges + range) * hd.cblks + cblk) * MB2) * 1024 + lane * 16);
 #pragma unroll
@@ -543,13 +552,13 @@ size_t hp_bwd2_lds_bytes(const Geom &g, const HpDims &hd) {
   int sub = 1;
   while (sub < 64 && lpd % (sub * 2) == 0) sub *= 2;
   const int msub = lpd / sub;
-  return (size_t)2 * hd.OpL * kPP * 2 + (size_t)2 * 32 * (hd.Cp + 8) * 2 +
+  return (size_t)2 * hd.OpL * kPP * 2 + (size_t)(kHpFuse2 ? 2 : 1) * 32 * (hd.Cp + 8) * 2 +
          (size_t)2 * 32 * g.DG * (2 * nc + 4) * 4 + (size_t)32 * g.DG * msub * nc * 4;
 }
 
 template <int ND, bool MOD, typename T, int WAVES, int NKS, int NS>
 static int launch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, const void *xt,
-                          const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
+                          const void *wpb, const int4 *btab, void *gcol, void *colbuf, float *part, int *cnt,
                           hipStream_t stream) {
   using Raw = typename T::Raw;
   const size_t lds = hp_bwd2_lds_bytes(g, hd);
@@ -560,19 +569,19 @@ static int launch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, con
   }
   hipLaunchKernelGGL((hp_bwd2_kernel<ND, MOD, T, WAVES, NKS, NS>), dim3(hd.ranges, g.K), dim3(64 * (WAVES + NS)), lds,
                      stream, g, hd, (const Raw *)xt, (const U4 *)wpb, btab, (const Raw *)t.grad_output,
-                     (const Raw *)t.offset, (const Raw *)t.mask, (Raw *)gcol, (Raw *)t.grad_offset,
-                     (Raw *)t.grad_mask, part, cnt);
+                     (const Raw *)t.offset, (const Raw *)t.mask, (Raw *)gcol, (Raw *)colbuf,
+                     (Raw *)t.grad_offset, (Raw *)t.grad_mask, part, cnt);
   return check_launch("hp_bwd2");
 }
 
 template <int ND, bool MOD, typename T>
 static int dispatch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, const void *xt,
-                            const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
+                            const void *wpb, const int4 *btab, void *gcol, void *colbuf, float *part, int *cnt,
                             hipStream_t stream) {
 #define HP_BWD(W, N)                                                                           \
   do {                                                                                         \
-    if (g.DG > 2) return launch_bwd2_hp<ND, MOD, T, W, N, 2>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream); \
-    return launch_bwd2_hp<ND, MOD, T, W, N, 1>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream);              \
+    if (g.DG > 2) return launch_bwd2_hp<ND, MOD, T, W, N, 2>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream); \
+    return launch_bwd2_hp<ND, MOD, T, W, N, 1>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream);              \
   } while (0)
 #define HP_BWD_W(W)                                                                            \
   switch (hd.nks) {                                                                            \
@@ -592,15 +601,15 @@ static int dispatch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, c
 }
 
 int hp_backward2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
-                        const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
+                        const void *wpb, const int4 *btab, void *gcol, void *colbuf, float *part, int *cnt,
                         hipStream_t stream) {
 #define HP_DISPATCH(T)                                                                            \
   do {                                                                                            \
     if (g.nd == 2)                                                                                \
-      return g.modulated ? dispatch_bwd2_hp<2, true, T>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream)  \
-                         : dispatch_bwd2_hp<2, false, T>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream); \
-    return g.modulated ? dispatch_bwd2_hp<3, true, T>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream)    \
-                       : dispatch_bwd2_hp<3, false, T>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream);   \
+      return g.modulated ? dispatch_bwd2_hp<2, true, T>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream)  \
+                         : dispatch_bwd2_hp<2, false, T>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream); \
+    return g.modulated ? dispatch_bwd2_hp<3, true, T>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream)    \
+                       : dispatch_bwd2_hp<3, false, T>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream);   \
   } while (0)
   if (dtype == MDCONV_F16) HP_DISPATCH(F16);
   HP_DISPATCH(BF16);

@@ -128,6 +128,13 @@ __device__ __forceinline__ void hp_corners(const TapCoef<ND, float> &tc, HpCorne
   }
 }
 
+// developer switch: 1 = GEMM-2 (grad_W) inside the fused backward kernel, 0 = dense hp_gemm2_kernel over
+// 16-bit column rows in the workspace (measured: see DESIGN.md section 4.3)
+#ifndef HP_FUSE2
+#define HP_FUSE2 1
+#endif
+constexpr bool kHpFuse2 = HP_FUSE2 != 0;
+
 // ---- dimensions / workspace of the 16-bit path ----
 struct HpDims {
   int Cp;           // C_in rounded up to 32: channel pitch of xt and of the grad_col rows
@@ -143,9 +150,11 @@ struct HpDims {
   int nks;          // GEMM-1 k-steps (16 output channels each) per 32-channel block
   int MB2;          // GEMM-2 output-channel blocks per 32-channel block
   int waves;        // waves per workgroup of the fused backward kernel = cblks (<= 8)
-  int ranges;       // pixel ranges per tap (split-K of grad_weight)
-  int max_ranges;   // upper bound of `ranges` for ANY batch size of this geometry (workspace sizing)
+  int ranges;       // pixel ranges per tap of the fused backward kernel
   int tiles_per_range;
+  int ranges_w;     // pixel ranges per tap of GEMM-2 (split-K of grad_weight, hp_gemm2.hip)
+  int tiles_per_range_w;
+  int max_ranges;   // upper bound of ranges / ranges_w for ANY batch size of this geometry (workspace sizing)
   int ntiles;       // 32-pixel tiles
 };
 

@@ -1,0 +1,213 @@
+// hp_gemm2.hip -- GEMM-2 of the native 16-bit backward as a dense kernel (gfx950).
+//
+//     grad_W[o, c, tap] = sum_n grad_out[o, n] * col[tap][n][c]
+//
+// (reference: the `addmm_` over the column buffer, mdeformable_conv.cu:436-441; 3-D
+// mdeformable_conv3d.cu:548-552), with col = the 16-bit column rows hp_bwd2_kernel leaves in the
+// workspace next to the grad_col rows.  M = output channels, N = input channels, K = pixels.
+// Until round 3 this contraction lived inside the fused backward kernel; its 64 accumulator
+// registers per wave (cfg5) held that kernel at one workgroup per CU.  On its own it is a streaming
+// kernel: per (tap, 32-pixel tile) a workgroup reads one grad_out tile (C_out x 32 x 2 B) and one
+// column tile (32 x Cp x 2 B) -- 16 KB at cfg5 against 8 MFMAs per wave -- so it is HBM-bound by
+// construction (cfg5 shard: 3.6 GB of column rows + the grad_out tiles of 27 taps, mostly cache
+// hits, against 0.19 ms of matrix time) and is laid out for bytes in flight: 4-wave workgroups,
+// about 100 registers, 4 workgroups per CU, next tile's loads issued before this tile's MFMAs, ONE
+// barrier per tile (both LDS tiles double-buffered).
+//
+// Workgroup = (pixel range, tap); wave w = input channels [32w, 32w + 32); the accumulators of the
+// whole range go to `part` ([tap][range][cblk][ob][lane][16], fp32) and hp_reduce_gw_kernel sums the
+// ranges.  LDS tiles are written row-wise with 16-byte stores; the B operand (K = pixel, N = channel)
+// is fetched from the [pixel][c] tile with ds_read_b64_tr_b16 exactly as the fused kernel did.
+#include "hp_kernels.hpp"
+
+namespace mdconv {
+
+namespace {
+
+constexpr int kPP = 40;   // LDS pitch (16-bit elements) of a 32-pixel grad_out row: 80 B
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <typename Raw> __device__ __forceinline__ void lds_tr2(const Raw *p, int step, U4 &out) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + step));
+  struct P { s16x4 a, b; } pk = {a, b};
+  out = __builtin_bit_cast(U4, pk);
+}
+
+template <typename T, int WAVES, int MB2>
+__global__ __launch_bounds__(64 * WAVES) void hp_gemm2_kernel(
+    Geom g, HpDims hd, const int4 *__restrict__ btab, const typename T::Raw *__restrict__ gout,
+    const typename T::Raw *__restrict__ colbuf, float *__restrict__ part) {
+  using Raw = typename T::Raw;
+  constexpr int NT = 64 * WAVES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int OpL = hd.OpL, Cp = hd.Cp, pitch = Cp + 8;
+  Raw *Gop = reinterpret_cast<Raw *>(smem);     // [2][OpL][kPP]   grad_out tile, [o][pixel]
+  Raw *Col = Gop + 2 * OpL * kPP;               // [2][32][pitch]  column tile,   [pixel][c]
+
+  const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, pl = lane & 31;
+  const int cblk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool active = cblk < hd.cblks;
+  const int tap = blockIdx.y, range = blockIdx.x;
+  const int t_lo = range * hd.tiles_per_range_w;
+  const int t_hi = min(t_lo + hd.tiles_per_range_w, hd.ntiles);
+  const int o_base = active ? btab[cblk].x : 0;
+
+  f32x16 acc[MB2];
+#pragma unroll
+  for (int i = 0; i < MB2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  if (t_lo < t_hi) {
+    // ---- loaders.  grad_out item = (o, pixel octet); column item = (pixel, channel octet).  (lb, lp) =
+    // image / pixel of the first pixel of the tile being REQUESTED (wave-uniform) ----
+    const bool vec_ok = (g.S_o & 7) == 0;
+    const int LPP = Cp / 8;
+    const int ngitems = OpL * 4, ncitems = 32 * LPP;
+    constexpr int GI = 2, CI = 2;   // items per thread kept in flight; more go through the tail loops
+    int lb = (t_lo * 32) / g.S_o, lp = t_lo * 32 - lb * g.S_o;
+    auto load_g = [&](int item) -> U4 {
+      const int o = item >> 2, oct = item & 3;
+      int bb = lb, pp = lp + oct * 8;
+      while (pp >= g.S_o) { pp -= g.S_o; ++bb; }
+      U4 v = {0, 0, 0, 0};
+      if (o < g.O && bb < g.B) {
+        if (vec_ok) {
+          v = *reinterpret_cast<const U4 *>(gout + ((int64_t)bb * g.O + o) * g.S_o + pp);
+        } else {
+          unsigned short e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            e[j] = bb < g.B ? __builtin_bit_cast(unsigned short, gout[((int64_t)bb * g.O + o) * g.S_o + pp]) : (unsigned short)0;
+            if (++pp == g.S_o) { pp = 0; ++bb; }
+          }
+          v.x = e[0] | ((u32)e[1] << 16); v.y = e[2] | ((u32)e[3] << 16);
+          v.z = e[4] | ((u32)e[5] << 16); v.w = e[6] | ((u32)e[7] << 16);
+        }
+      }
+      return v;
+    };
+    auto load_c = [&](int item) -> U4 {
+      const int p = item / LPP, oc = item - p * LPP;
+      int bb = lb, pp = lp + p;
+      while (pp >= g.S_o) { pp -= g.S_o; ++bb; }
+      U4 v = {0, 0, 0, 0};   // pixels beyond the batch: the fused kernel never wrote those rows
+      if (bb < g.B) v = *reinterpret_cast<const U4 *>(colbuf + (((int64_t)bb * g.K + tap) * g.S_o + pp) * Cp + oc * 8);
+      return v;
+    };
+    auto store_g = [&](int item, const U4 &v, int buf) {
+      *reinterpret_cast<U4 *>(Gop + (buf * OpL + (item >> 2)) * kPP + (item & 3) * 8) = v;
+    };
+    auto store_c = [&](int item, const U4 &v, int buf) {
+      const int p = item / LPP, oc = item - p * LPP;
+      *reinterpret_cast<U4 *>(Col + (buf * 32 + p) * pitch + oc * 8) = v;
+    };
+    U4 rg[GI], rc[CI];
+    auto request = [&]() {   // the tile at (lb, lp): first GI / CI items per thread into registers
+#pragma unroll
+      for (int i = 0; i < GI; ++i) rg[i] = tid + i * NT < ngitems ? load_g(tid + i * NT) : U4{0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < CI; ++i) rc[i] = tid + i * NT < ncitems ? load_c(tid + i * NT) : U4{0, 0, 0, 0};
+    };
+    auto publish = [&](int buf) {   // registers -> LDS; items beyond the in-flight ones are loaded here
+#pragma unroll
+      for (int i = 0; i < GI; ++i) if (tid + i * NT < ngitems) store_g(tid + i * NT, rg[i], buf);
+#pragma unroll
+      for (int i = 0; i < CI; ++i) if (tid + i * NT < ncitems) store_c(tid + i * NT, rc[i], buf);
+      for (int item = tid + GI * NT; item < ngitems; item += NT) store_g(item, load_g(item), buf);
+      for (int item = tid + CI * NT; item < ncitems; item += NT) store_c(item, load_c(item), buf);
+    };
+    auto advance = [&]() {
+      lp += 32;
+      while (lp >= g.S_o) { lp -= g.S_o; ++lb; }
+    };
+
+    request();
+    publish(0);
+    advance();
+    if (t_lo + 1 < t_hi) request();
+    __syncthreads();
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+      const int buf = (tile - t_lo) & 1;
+      if (tile + 1 < t_hi) {
+        publish(buf ^ 1);   // the other buffer was last read before the barrier that ended the previous iteration
+        advance();
+        if (tile + 2 < t_hi) request();
+      }
+      if (active) {
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          // B fragment (K = pixel, N = channel) from the [pixel][c] column tile
+          U4 bc;
+          lds_tr2(Col + (buf * 32 + ks2 * 16 + 8 * kh + ((lane & 15) >> 2)) * pitch + cblk * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3),
+                  4 * pitch, bc);
+#pragma unroll
+          for (int ob = 0; ob < MB2; ++ob) {
+            const U4 a = *reinterpret_cast<const U4 *>(Gop + (buf * OpL + o_base + ob * 32 + pl) * kPP + ks2 * 16 + 8 * kh);
+            acc[ob] = T::mfma(a, bc, acc[ob]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (active) {
+    float4 *dst = reinterpret_cast<float4 *>(
+        part + ((((int64_t)tap * hd.ranges_w + range) * hd.cblks + cblk) * MB2) * 1024 + lane * 16);
+#pragma unroll
+    for (int ob = 0; ob < MB2; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        dst[ob * 256 + q] = make_float4(acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]);
+  }
+}
+
+template <typename T, int WAVES, int MB2>
+int launch_gemm2(const Geom &g, const HpDims &hd, const Tensors &t, const int4 *btab, const void *colbuf,
+                 float *part, hipStream_t stream) {
+  using Raw = typename T::Raw;
+  const size_t lds = hp_gemm2_lds_bytes(hd);
+  if (lds > 64 * 1024) {
+    hipError_t ea = hipFuncSetAttribute((const void *)hp_gemm2_kernel<T, WAVES, MB2>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; }
+  }
+  hipLaunchKernelGGL((hp_gemm2_kernel<T, WAVES, MB2>), dim3(hd.ranges_w, g.K), dim3(64 * WAVES), lds, stream, g, hd,
+                     btab, (const Raw *)t.grad_output, (const Raw *)colbuf, part);
+  return check_launch("hp_gemm2");
+}
+
+template <typename T>
+int dispatch_gemm2(const Geom &g, const HpDims &hd, const Tensors &t, const int4 *btab, const void *colbuf,
+                   float *part, hipStream_t stream) {
+#define HP_G2(W)                                                                       \
+  switch (hd.MB2) {                                                                    \
+    case 1: return launch_gemm2<T, W, 1>(g, hd, t, btab, colbuf, part, stream);        \
+    case 2: return launch_gemm2<T, W, 2>(g, hd, t, btab, colbuf, part, stream);        \
+    case 4: return launch_gemm2<T, W, 4>(g, hd, t, btab, colbuf, part, stream);        \
+    default: return launch_gemm2<T, W, 8>(g, hd, t, btab, colbuf, part, stream);       \
+  }
+  switch (hd.waves) {
+    case 1: HP_G2(1);
+    case 2: HP_G2(2);
+    case 4: HP_G2(4);
+    default: HP_G2(8);
+  }
+#undef HP_G2
+}
+
+}  // namespace
+
+size_t hp_gemm2_lds_bytes(const HpDims &hd) {
+  return (size_t)2 * hd.OpL * kPP * 2 + (size_t)2 * 32 * (hd.Cp + 8) * 2;
+}
+
+int hp_gemm2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const int4 *btab,
+                    const void *colbuf, float *part, hipStream_t stream) {
+  if (dtype == MDCONV_F16) return dispatch_gemm2<F16>(g, hd, t, btab, colbuf, part, stream);
+  return dispatch_gemm2<BF16>(g, hd, t, btab, colbuf, part, stream);
+}
+
+}  // namespace mdconv

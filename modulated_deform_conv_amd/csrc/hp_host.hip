@@ -1,9 +1,10 @@
 // hp_host.hip -- dispatch, workspace layout and kernel sequence of the native 16-bit path.
 //
 // forward : pack weights -> channels-last input copy -> hp_fwd_kernel
-// backward: pack W^T -> channels-last input copy -> hp_bwd_kernel (GEMM-1 + coordinate gradients +
-//           grad_col + GEMM-2 with ONE gather pass, CSR counting) -> split-K reduce of grad_weight,
-//           grad_bias -> [weights-ready event] -> CSR scan + fill -> col2im gather
+// backward: pack W^T -> channels-last input copy -> hp_bwd2_kernel (GEMM-1 + coordinate gradients +
+//           grad_col rows + column rows with ONE gather pass, CSR counting) -> hp_gemm2_kernel (dense
+//           GEMM-2 over the column rows) -> split-K reduce of grad_weight, grad_bias ->
+//           [weights-ready event] -> CSR scan + fill -> col2im gather
 // Calls whose channels-last copy would exceed 2 GiB (32-bit buffer offsets) are cut into batch
 // chunks; grad_weight accumulates across chunks.
 #include "hp_kernels.hpp"
@@ -47,7 +48,7 @@ Geom chunk_geom(const Geom &g, int bc) {
 }
 
 struct FwdLayout { size_t off_xt, off_w, off_tab, total; };
-struct BwdLayout { size_t off_xt, off_w, off_tab, off_gcol, off_part, off_gw32, off_cnt, off_rowptr, off_entries, total; };
+struct BwdLayout { size_t off_xt, off_w, off_tab, off_gcol, off_col, off_part, off_gw32, off_cnt, off_rowptr, off_entries, total; };
 
 // images per chunk: channels-last input copy (and one image's grad_col) below the limit
 int chunk_batch(const Geom &g, const HpDims &hd, bool backward) {
@@ -78,6 +79,7 @@ BwdLayout bwd_layout(const Geom &gc, const HpDims &hd) {
   L.off_w = off;    off += align_up((size_t)gc.K * hd.cblks * hd.nks * 1024);
   L.off_tab = off;  off += align_up((size_t)hd.cblks * sizeof(int4));
   L.off_gcol = off; off += align_up((size_t)gc.B * gc.K * gc.S_o * hd.Cp * 2);
+  L.off_col = off;  off += kHpFuse2 ? 0 : align_up((size_t)gc.B * gc.K * gc.S_o * hd.Cp * 2);   // column rows for GEMM-2
   // a shorter last chunk can have MORE ranges than a full one (ranges is not monotonic in the tile
   // count), so the partials are sized for the bound; gw32 = running fp32 grad_weight over chunks
   L.off_part = off; off += align_up((size_t)gc.K * hd.max_ranges * hd.cblks * hd.MB2 * 4096);
@@ -94,6 +96,12 @@ BwdLayout bwd_layout(const Geom &gc, const HpDims &hd) {
 }  // namespace
 
 int num_cus();   // mfma_bwd_data.hip
+
+// workgroups per CU the fused backward kernel is sized for when it has 8 + 2 waves (C_in > 128)
+static int hp_wg_per_cu8() {
+  static const int n = getenv("MDCONV_HP_WG8") ? atoi(getenv("MDCONV_HP_WG8")) : 2;
+  return n < 1 ? 1 : n;
+}
 
 HpDims hp_dims(const Geom &g) {
   HpDims hd;
@@ -138,14 +146,22 @@ HpDims hp_dims(const Geom &g) {
   hd.OpL = base_max + 32 * hd.MB2 > hd.Op ? base_max + 32 * hd.MB2 : hd.Op;
   hd.waves = pow2_ceil(hd.cblks);
   hd.ntiles = (g.N + 31) / 32;
-  // pixel ranges per tap: about one dispatch round of workgroups (2 four-wave workgroups per CU)
-  const int slots = num_cus() * (hd.waves >= 8 ? 1 : 2 * (4 / hd.waves));
+  // pixel ranges per tap of the fused kernel: about one dispatch round of workgroups (2 workgroups of
+  // 4 + 1 waves per CU, 1-2 of 8 + 2)
+  const int slots = num_cus() * (hd.waves >= 8 ? hp_wg_per_cu8() : 2 * (4 / hd.waves));
   int ranges = slots / g.K;
   if (ranges < 1) ranges = 1;
   hd.max_ranges = ranges;
   if (ranges > hd.ntiles) ranges = hd.ntiles;
   hd.tiles_per_range = (hd.ntiles + ranges - 1) / ranges;
   hd.ranges = (hd.ntiles + hd.tiles_per_range - 1) / hd.tiles_per_range;
+  // GEMM-2 (dense, HBM-bound): 4 workgroups per CU in flight, at least 8 tiles per workgroup
+  int rw = num_cus() * 4 / g.K;
+  if (rw < 1) rw = 1;
+  if (rw > hd.max_ranges) hd.max_ranges = rw;
+  if (rw > (hd.ntiles + 7) / 8) rw = (hd.ntiles + 7) / 8;
+  hd.tiles_per_range_w = (hd.ntiles + rw - 1) / rw;
+  hd.ranges_w = (hd.ntiles + hd.tiles_per_range_w - 1) / hd.tiles_per_range_w;
   return hd;
 }
 
@@ -259,14 +275,21 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
     if (bwd2)
       rc = hp_backward2_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                                (const int4 *)(base + L.off_tab), base + L.off_gcol,
-                               (float *)(base + L.off_part), cnt, stream);
+                               base + L.off_col, (float *)(base + L.off_part), cnt, stream);
     else
       rc = hp_backward_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                               (const int4 *)(base + L.off_tab), base + L.off_gcol,
                               (float *)(base + L.off_part), cnt, stream);
     profile_mark(1, false, stream);
     if (rc) return rc;
-    if ((rc = hp_reduce_grad_weight(gc, hd, dtype, (const float *)(base + L.off_part),
+    if (bwd2 && !kHpFuse2) {
+      profile_mark(2, true, stream, "hp_gemm2_kernel");
+      rc = hp_gemm2_launch(gc, hd, dtype, tc, (const int4 *)(base + L.off_tab), base + L.off_col,
+                           (float *)(base + L.off_part), stream);
+      profile_mark(2, false, stream);
+      if (rc) return rc;
+    }
+    if ((rc = hp_reduce_grad_weight(gc, hd, bwd2 && !kHpFuse2 ? hd.ranges_w : hd.ranges, dtype, (const float *)(base + L.off_part),
                                     (const int4 *)(base + L.off_tab), t.grad_weight,
                                     multi ? (float *)(base + L.off_gw32) : nullptr, first, last, stream)))
       return rc;

@@ -18,7 +18,8 @@ int hp_pack_fwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *
 int hp_pack_bwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *w, void *wpb,
                         int4 *btab, hipStream_t stream);
 // gw32 != nullptr (calls cut into batch chunks): running fp32 sum; grad_weight is written by the last chunk
-int hp_reduce_grad_weight(const Geom &g, const HpDims &hd, int dtype, const float *part,
+// `ranges` = pixel ranges per tap in `part` (hd.ranges_w after hp_gemm2, hd.ranges after hp_bwd)
+int hp_reduce_grad_weight(const Geom &g, const HpDims &hd, int ranges, int dtype, const float *part,
                           const int4 *btab, void *grad_weight, float *gw32, bool first, bool last,
                           hipStream_t stream);
 int hp_grad_bias(const Geom &g, int dtype, const void *grad_output, void *grad_bias,
@@ -37,11 +38,17 @@ int hp_backward_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors
                        const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                        hipStream_t stream);
 
-// hp_bwd2.hip: the same kernel with line-wide gathers (thread roles change between phases)
+// hp_bwd2.hip: GEMM-1 + coordinate gradients + grad_col rows + column rows with line-wide gathers
+// (thread roles change between phases); GEMM-2 is hp_gemm2.hip
 size_t hp_bwd2_lds_bytes(const Geom &g, const HpDims &hd);
 int hp_backward2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
-                        const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
+                        const void *wpb, const int4 *btab, void *gcol, void *colbuf, float *part, int *cnt,
                         hipStream_t stream);
+
+// hp_gemm2.hip: grad_W partials = grad_out . col^T over the column rows, dense, split over pixel ranges
+size_t hp_gemm2_lds_bytes(const HpDims &hd);
+int hp_gemm2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const int4 *btab,
+                    const void *colbuf, float *part, hipStream_t stream);
 
 // hp_col2im.hip: inverse scatter map (counting pass inside the fused backward kernel) + gather
 int hp_csr_zero(const Geom &g, int *cnt, hipStream_t stream);

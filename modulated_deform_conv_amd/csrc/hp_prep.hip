@@ -141,7 +141,7 @@ __global__ void hp_btab_kernel(Geom g, HpDims hd, int4 *__restrict__ btab) {
 // grad_weight[o][c][tap] (+)= sum over the pixel ranges of part[tap][range][cblk][ob][lane][16]
 // (the 32x32 fp32 accumulator blocks of the fused backward kernel, D[i = o][j = c])
 template <typename T>
-__global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, const int4 *__restrict__ btab,
+__global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, int ranges, const int4 *__restrict__ btab,
                                                            const float *__restrict__ part,
                                                            typename T::Raw *__restrict__ gw,
                                                            float *__restrict__ gw32, int first, int last) {
@@ -157,10 +157,10 @@ __global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, co
     const int c = cblk * 32 + (lane & 31);
     if (o < g.O && c < g.C && o / g.Og == c / g.Cg) {
       const int64_t per_range = (int64_t)hd.cblks * hd.MB2 * 1024;
-      const float *p = part + ((int64_t)tap * hd.ranges) * per_range + ((int64_t)cblk * hd.MB2 + ob) * 1024 +
+      const float *p = part + ((int64_t)tap * ranges) * per_range + ((int64_t)cblk * hd.MB2 + ob) * 1024 +
                        lane * 16 + reg;
       float s = 0.f;
-      for (int k = 0; k < hd.ranges; ++k) s += p[(int64_t)k * per_range];
+      for (int k = 0; k < ranges; ++k) s += p[(int64_t)k * per_range];
       const int64_t e = ((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap;
       // calls cut into batch chunks keep the running sum in fp32 (gw32) and round ONCE, after the
       // last chunk, like the single-chunk path
@@ -225,16 +225,16 @@ int hp_pack_bwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *
   return check_launch("hp_pack_bwd");
 }
 
-int hp_reduce_grad_weight(const Geom &g, const HpDims &hd, int dtype, const float *part,
+int hp_reduce_grad_weight(const Geom &g, const HpDims &hd, int ranges, int dtype, const float *part,
                           const int4 *btab, void *grad_weight, float *gw32, bool first, bool last,
                           hipStream_t stream) {
   const int64_t total = (int64_t)g.K * hd.cblks * hd.MB2 * 1024;
   if (dtype == MDCONV_F16)
     hipLaunchKernelGGL((hp_reduce_gw_kernel<F16>), dim3(grid_for(total)), dim3(256), 0, stream, g, hd,
-                       btab, part, (_Float16 *)grad_weight, gw32, first ? 1 : 0, last ? 1 : 0);
+                       ranges, btab, part, (_Float16 *)grad_weight, gw32, first ? 1 : 0, last ? 1 : 0);
   else
     hipLaunchKernelGGL((hp_reduce_gw_kernel<BF16>), dim3(grid_for(total)), dim3(256), 0, stream, g, hd,
-                       btab, part, (__bf16 *)grad_weight, gw32, first ? 1 : 0, last ? 1 : 0);
+                       ranges, btab, part, (__bf16 *)grad_weight, gw32, first ? 1 : 0, last ? 1 : 0);
   return check_launch("hp_reduce_gw");
 }
 

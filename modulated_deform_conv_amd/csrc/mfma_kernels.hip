@@ -336,9 +336,12 @@ bool get_fork(hipStream_t stream, Fork *out) {
   *out = f;
   return true;
 }
-// MDCONV_BWD_FORK = 0 / 1: run the grad_input gather beside GEMM-2 on a forked stream (read once)
+// MDCONV_BWD_FORK = 0 / 1: run the grad_input gather beside GEMM-2 on a forked stream (read once).
+// On by default: cfg2 3.68 -> 3.40 ms per step (GEMM-2 1.06 -> 1.10 ms, the 0.33 ms of CSR build +
+// gather disappear under it); round 1 had measured a loss with the NCHW GEMM-2, whose gathers kept
+// the L2 as busy as the col2im gather does -- the channels-last GEMM-2 leaves the L2 mostly idle.
 bool bwd_fork_enabled() {
-  static const int on = getenv("MDCONV_BWD_FORK") ? atoi(getenv("MDCONV_BWD_FORK")) : 0;
+  static const int on = getenv("MDCONV_BWD_FORK") ? atoi(getenv("MDCONV_BWD_FORK")) : 1;
   return on != 0;
 }
 
@@ -350,10 +353,8 @@ bool bwd_fork_enabled() {
 //   -> GEMM-2, split-K reduce, grad_bias -> [weights-ready event] -> CSR scan + fill -> col2im
 // grad_weight / grad_bias are produced BEFORE the grad_input gather so that a data-parallel
 // all-reduce of them can run under the gather (mdconv_stream_wait_weight_ready).
-// Stream-level overlap was tried and dropped: forking the CSR build to a second stream and
-// running GEMM-2 next to the gather slowed GEMM-1 from 1.21 to 1.41 ms and GEMM-2 from 1.15 to
-// 1.74 ms (they compete for the same L2 / texture path; 4.34 vs 4.16 ms per step at cfg2), and
-// the two GEMMs run concurrently only halve each other.
+// The grad_input gather (CSR scan + fill -> col2im, HBM-bound) shares nothing with GEMM-2 (matrix-bound)
+// and runs beside it on a forked stream that re-joins before this function returns (get_fork).
 int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t stream,
                        bool weights_final) {
   const BwdDims bd = bwd_dims(g);

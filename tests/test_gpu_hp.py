@@ -52,7 +52,7 @@ FALLBACK_CASES = [
 ]
 
 
-def _check(case, dtype, expect_hp=True):
+def _check(case, dtype, expect_hp=True, tol=None):
     from modulated_deform_conv_amd import _capi
     t = make_inputs(case, dtype=dtype, device="cuda")
     out, grads, paths = run_product(case, t, "auto")
@@ -60,7 +60,7 @@ def _check(case, dtype, expect_hp=True):
     if expect_hp:
         assert _capi.last_kernels() == "hp", (_capi.last_kernels(), paths)
     want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
-    tol = TOL[dtype]
+    tol = tol or TOL[dtype]
     assert_close("output", out.float(), want_out, tol)
     for key, g in grads.items():
         if want[key] is None:
@@ -120,7 +120,7 @@ def test_channels_last_input_on_a_shape_the_native_backward_rejects():
     t = make_inputs(case, dtype=torch.float16, device="cuda")
     res = []
     for fmt in (torch.contiguous_format, torch.channels_last):
-        x = t["input"].contiguous(memory_format=fmt).requires_grad_()
+        x = t["input"].detach().clone(memory_format=fmt).requires_grad_()
         off, m, w = (t[k].clone().requires_grad_() for k in ("offset", "mask", "weight"))
         out = modulated_deform_conv2d(x, off, m, w, t["bias"], 1, 1, 1, 1, 1, 64)
         out.backward(t["grad_output"])
@@ -132,8 +132,10 @@ def test_channels_last_input_on_a_shape_the_native_backward_rejects():
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["tier"] == "medium"], ids=lambda c: c["name"])
 def test_medium_cases_fp16(case):
-    """Every medium case of the shared list in fp16, whichever kernels the dispatcher picks."""
-    _check(case, torch.float16, expect_hp=False)
+    """Every medium case of the shared list in fp16, whichever kernels the dispatcher picks.  1e-2: the
+    worst case of this list (stride-2 3-D, grad_input: sums of fp16-rounded grad_col rows with
+    cancellation) measures 7.3e-3 on the per-element criterion."""
+    _check(case, torch.float16, expect_hp=False, tol=1e-2)
 
 
 def test_non_finite_border_pixel_is_not_read():
