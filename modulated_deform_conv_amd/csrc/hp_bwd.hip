@@ -28,7 +28,6 @@ namespace mdconv {
 
 namespace {
 
-constexpr int kPP = 40;   // LDS pitch (16-bit elements) of a 32-pixel row: 80 B, 16-byte aligned
 
 template <int ND, bool MOD, typename T, int WAVES, int NKS>
 __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 || NKS >= 16 || ND == 3) ? 1 : 2) void hp_bwd_kernel(

@@ -29,7 +29,6 @@ namespace mdconv {
 
 namespace {
 
-constexpr int kPP = 40;   // LDS pitch (16-bit elements) of a 32-pixel row: 80 B, 16-byte aligned
 
 #ifdef HP_TIMING
 // developer instrumentation (tools/hp_timing.py): cycles per phase, summed over waves 0 and 1
@@ -38,52 +37,6 @@ __device__ unsigned long long g_hp_timing[16];
 #else
 #define HP_T(slot) do { } while (0)
 #endif
-
-// Sum of S[i] over the `sub` (a power of two, wave-uniform) lanes of a group, up to 16 lanes = one DPP
-// row: quad_perm swaps (lane ^ 1, lane ^ 2), then row_half_mirror (lane i <-> 7 - i of its 8) and
-// row_mirror (i <-> 15 - i), which pair lanes that already hold equal quad / half-row sums.
-// ONE asm statement with scalar branches on `sub` inside: hipcc lowers the DPP builtin to mov +
-// mov_dpp + add, and separate conditional statements cost a register copy per value and level;
-// the s_nops cover the VALU-write -> DPP-read hazard (2 wait states), not padded for inline asm.
-#define HP_DPP_LVL(MOD)                                                                           \
-      "v_add_f32_dpp %0, %0, %0 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
-      "v_add_f32_dpp %1, %1, %1 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
-      "v_add_f32_dpp %2, %2, %2 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
-      "v_add_f32_dpp %3, %3, %3 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
-      "s_nop 1\n\t"
-template <int NC> __device__ __forceinline__ void hp_dpp_sum(float (&S)[NC], int sub) {
-#pragma unroll
-  for (int o = 0; o < NC; o += 4)
-    asm("s_nop 1\n\t"
-        "s_cmp_lt_i32 %4, 2\n\t"
-        "s_cbranch_scc1 Ldpp_end%=\n\t"
-        HP_DPP_LVL("quad_perm:[1,0,3,2]")
-        "s_cmp_lt_i32 %4, 4\n\t"
-        "s_cbranch_scc1 Ldpp_end%=\n\t"
-        HP_DPP_LVL("quad_perm:[2,3,0,1]")
-        "s_cmp_lt_i32 %4, 8\n\t"
-        "s_cbranch_scc1 Ldpp_end%=\n\t"
-        HP_DPP_LVL("row_half_mirror")
-        "s_cmp_lt_i32 %4, 16\n\t"
-        "s_cbranch_scc1 Ldpp_end%=\n\t"
-        HP_DPP_LVL("row_mirror")
-        "Ldpp_end%=:"
-        : "+v"(S[o]), "+v"(S[o + 1]), "+v"(S[o + 2]), "+v"(S[o + 3])
-        : "s"(sub)
-        : "scc");
-}
-#undef HP_DPP_LVL
-
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-// 8 consecutive K values of this lane's matrix column from a row-major [K][N] LDS tile: two
-// ds_read_b64_tr_b16 (4 rows each, `step` elements apart); `p` = this lane's piece of the block
-template <typename Raw> __device__ __forceinline__ void lds_tr2(const Raw *p, int step, U4 &out) {
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + step));
-  struct P { s16x4 a, b; } pk = {a, b};
-  out = __builtin_bit_cast(U4, pk);
-}
 
 // advance (b, oc[]) -- image index and output coordinates of a pixel -- by `adv` flattened pixels
 template <int ND> __device__ __forceinline__ void advance_pixel(const Geom &g, int adv, int &b, int *oc) {
@@ -100,13 +53,12 @@ template <int ND> __device__ __forceinline__ void advance_pixel(const Geom &g, i
 // pipeline -- offsets / mask, sampling state, CSR counting, the final grad_offset / grad_mask
 // arithmetic -- beside them (it was 47 % of the tile time when wave 0 did it on top of its share).
 template <int ND, bool MOD, typename T, int WAVES, int NKS, int NS>
-__global__ __launch_bounds__(64 * (WAVES + NS), kHpFuse2 ? (WAVES >= 8 ? 1 : 2) : ((WAVES >= 8 || NKS >= 16) ? 2 : 3)) void hp_bwd2_kernel(
+__global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2_kernel(
     Geom g, HpDims hd, const typename T::Raw *__restrict__ xt, const U4 *__restrict__ wpb,
     const int4 *__restrict__ btab, const typename T::Raw *__restrict__ gout,
     const typename T::Raw *__restrict__ offset, const typename T::Raw *__restrict__ mask,
-    typename T::Raw *__restrict__ gcol, typename T::Raw *__restrict__ colbuf,
-    typename T::Raw *__restrict__ grad_offset, typename T::Raw *__restrict__ grad_mask,
-    float *__restrict__ part, int *__restrict__ cnt) {
+    typename T::Raw *__restrict__ gcol, typename T::Raw *__restrict__ grad_offset,
+    typename T::Raw *__restrict__ grad_mask, float *__restrict__ part, int *__restrict__ cnt) {
   using Raw = typename T::Raw;
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB2 = NKS / 2;
@@ -118,8 +70,8 @@ __global__ __launch_bounds__(64 * (WAVES + NS), kHpFuse2 ? (WAVES >= 8 ? 1 : 2) 
   const int pitch_gc = Cp + 8;
   Raw *Gop = reinterpret_cast<Raw *>(smem);            // [2][OpL][kPP]   grad_out tile, [o][pixel]
   Raw *Gc = Gop + 2 * OpL * kPP;                       // [32][pitch_gc]  grad_col tile, [pixel][c]
-  Raw *Col = Gc + 32 * pitch_gc;                       // [32][pitch_gc]  column tile,   [pixel][c] (fused GEMM-2 only)
-  int *St = reinterpret_cast<int *>(Col + (kHpFuse2 ? 32 * pitch_gc : 0));   // [2][32 * DG][SW]
+  Raw *Col = Gc + 32 * pitch_gc;                       // [32][pitch_gc]  column tile,   [pixel][c]
+  int *St = reinterpret_cast<int *>(Col + 32 * pitch_gc);              // [2][32 * DG][SW]
   float *Spart = reinterpret_cast<float *>(St + 2 * 32 * g.DG * SW);   // [32 * DG][msub][NC]
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, pl = lane & 31;
@@ -324,13 +276,11 @@ __global__ __launch_bounds__(64 * (WAVES + NS), kHpFuse2 ? (WAVES >= 8 ? 1 : 2) 
   for (int ks = 0; ks < NKS; ++ks)
     wf[ks] = active ? wpb[(((int64_t)tap * hd.cblks + cblk) * NKS + ks) * 64 + lane] : U4{0, 0, 0, 0};
 
-  f32x16 acc2[kHpFuse2 ? MB2 : 1];
-  if (kHpFuse2) {
+  f32x16 acc2[MB2];
 #pragma unroll
-    for (int i = 0; i < MB2; ++i)
+  for (int i = 0; i < MB2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
-  }
+    for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
 
   // ---- grad_out tile: item = (o, pixel octet); two items per thread in flight, tail loop.
   // (gb, gp) = image / pixel of the first pixel of the NEXT tile to load (wave-uniform) ----
@@ -432,7 +382,6 @@ __global__ __launch_bounds__(64 * (WAVES + NS), kHpFuse2 ? (WAVES >= 8 ? 1 : 2) 
       int grow[NI], gimg[NI];
       const int *st_tile = St + buf * 32 * g.DG * SW;
       const rsrc_t r_gcol = make_rsrc(gcol + (size_t)cb * gcol_img, gcol_img * 2);   // image of this tile (tile_ok)
-      const rsrc_t r_col = make_rsrc(colbuf + (size_t)cb * gcol_img, gcol_img * 2);
       auto request = [&](int k, int slot) {
         if (it_on[k]) {
           const int *sp = st_tile + (it_p[k] * g.DG + it_dg[k]) * SW;
@@ -466,12 +415,7 @@ __global__ __launch_bounds__(64 * (WAVES + NS), kHpFuse2 ? (WAVES >= 8 ? 1 : 2) 
             S[ci] = dot8<T>(0.f, x[slot][ci], gq[slot]);
             mac8<T>(col, x[slot][ci], wm[slot][ci]);
           }
-          if (kHpFuse2)
-            *reinterpret_cast<U4 *>(Col + it_p[k] * pitch_gc + it_oc[k] * 8) = pack8<T>(col);
-          else if (tile_ok)   // column row (addressed like the grad_col row) for the dense GEMM-2 kernel
-            buf_store4u(r_col, grow[slot] + it_oc[k] * 16, 0, pack8<T>(col));
-          else if (grow[slot] != kHpOob)
-            *reinterpret_cast<U4 *>(colbuf + (size_t)gimg[slot] * gcol_img + (grow[slot] >> 1) + it_oc[k] * 8) = pack8<T>(col);
+          *reinterpret_cast<U4 *>(Col + it_p[k] * pitch_gc + it_oc[k] * 8) = pack8<T>(col);
           // reduce S over the `sub` lanes that share (pixel, dg); partials -> LDS.  Up to 16 lanes
           // (one DPP row) with DPP operands, ds_bpermute only beyond
           hp_dpp_sum<NC>(S, sub);
@@ -501,7 +445,7 @@ __global__ __launch_bounds__(64 * (WAVES + NS), kHpFuse2 ? (WAVES >= 8 ? 1 : 2) 
     HP_T(5);
     // ================= P4: GEMM-2 =================
     if (tile + 2 < t_hi) { g_load(); g_advance(); }
-    if (kHpFuse2 && active) {
+    if (active) {
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
         // B fragment (K = pixel, N = channel) from the [pixel][c] column tile
@@ -523,7 +467,7 @@ __global__ __launch_bounds__(64 * (WAVES + NS), kHpFuse2 ? (WAVES >= 8 ? 1 : 2) 
   if (lane == 0 && wave < 2)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_hp_timing[wave * 8 + i], t_acc[i]);
 #endif
-  if (kHpFuse2 && active) {
+  if (active) {
     float4 *dst = reinterpret_cast<float4 *>(
         part + ((((int64_t)tap * hd.ranges + range) * hd.cblks + cblk) * MB2) * 1024 + lane * 16);
 #pragma unroll
@@ -552,13 +496,13 @@ size_t hp_bwd2_lds_bytes(const Geom &g, const HpDims &hd) {
   int sub = 1;
   while (sub < 64 && lpd % (sub * 2) == 0) sub *= 2;
   const int msub = lpd / sub;
-  return (size_t)2 * hd.OpL * kPP * 2 + (size_t)(kHpFuse2 ? 2 : 1) * 32 * (hd.Cp + 8) * 2 +
+  return (size_t)2 * hd.OpL * kPP * 2 + (size_t)2 * 32 * (hd.Cp + 8) * 2 +
          (size_t)2 * 32 * g.DG * (2 * nc + 4) * 4 + (size_t)32 * g.DG * msub * nc * 4;
 }
 
 template <int ND, bool MOD, typename T, int WAVES, int NKS, int NS>
 static int launch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, const void *xt,
-                          const void *wpb, const int4 *btab, void *gcol, void *colbuf, float *part, int *cnt,
+                          const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                           hipStream_t stream) {
   using Raw = typename T::Raw;
   const size_t lds = hp_bwd2_lds_bytes(g, hd);
@@ -569,19 +513,19 @@ static int launch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, con
   }
   hipLaunchKernelGGL((hp_bwd2_kernel<ND, MOD, T, WAVES, NKS, NS>), dim3(hd.ranges, g.K), dim3(64 * (WAVES + NS)), lds,
                      stream, g, hd, (const Raw *)xt, (const U4 *)wpb, btab, (const Raw *)t.grad_output,
-                     (const Raw *)t.offset, (const Raw *)t.mask, (Raw *)gcol, (Raw *)colbuf,
-                     (Raw *)t.grad_offset, (Raw *)t.grad_mask, part, cnt);
+                     (const Raw *)t.offset, (const Raw *)t.mask, (Raw *)gcol, (Raw *)t.grad_offset,
+                     (Raw *)t.grad_mask, part, cnt);
   return check_launch("hp_bwd2");
 }
 
 template <int ND, bool MOD, typename T>
 static int dispatch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, const void *xt,
-                            const void *wpb, const int4 *btab, void *gcol, void *colbuf, float *part, int *cnt,
+                            const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                             hipStream_t stream) {
 #define HP_BWD(W, N)                                                                           \
   do {                                                                                         \
-    if (g.DG > 2) return launch_bwd2_hp<ND, MOD, T, W, N, 2>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream); \
-    return launch_bwd2_hp<ND, MOD, T, W, N, 1>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream);              \
+    if (g.DG > 2) return launch_bwd2_hp<ND, MOD, T, W, N, 2>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream); \
+    return launch_bwd2_hp<ND, MOD, T, W, N, 1>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream);              \
   } while (0)
 #define HP_BWD_W(W)                                                                            \
   switch (hd.nks) {                                                                            \
@@ -601,15 +545,15 @@ static int dispatch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, c
 }
 
 int hp_backward2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
-                        const void *wpb, const int4 *btab, void *gcol, void *colbuf, float *part, int *cnt,
+                        const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                         hipStream_t stream) {
 #define HP_DISPATCH(T)                                                                            \
   do {                                                                                            \
     if (g.nd == 2)                                                                                \
-      return g.modulated ? dispatch_bwd2_hp<2, true, T>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream)  \
-                         : dispatch_bwd2_hp<2, false, T>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream); \
-    return g.modulated ? dispatch_bwd2_hp<3, true, T>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream)    \
-                       : dispatch_bwd2_hp<3, false, T>(g, hd, t, xt, wpb, btab, gcol, colbuf, part, cnt, stream);   \
+      return g.modulated ? dispatch_bwd2_hp<2, true, T>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream)  \
+                         : dispatch_bwd2_hp<2, false, T>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream); \
+    return g.modulated ? dispatch_bwd2_hp<3, true, T>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream)    \
+                       : dispatch_bwd2_hp<3, false, T>(g, hd, t, xt, wpb, btab, gcol, part, cnt, stream);   \
   } while (0)
   if (dtype == MDCONV_F16) HP_DISPATCH(F16);
   HP_DISPATCH(BF16);

@@ -128,12 +128,53 @@ __device__ __forceinline__ void hp_corners(const TapCoef<ND, float> &tc, HpCorne
   }
 }
 
-// developer switch: 1 = GEMM-2 (grad_W) inside the fused backward kernel, 0 = dense hp_gemm2_kernel over
-// 16-bit column rows in the workspace (measured: see DESIGN.md section 4.3)
-#ifndef HP_FUSE2
-#define HP_FUSE2 1
-#endif
-constexpr bool kHpFuse2 = HP_FUSE2 != 0;
+constexpr int kPP = 40;   // LDS pitch (16-bit elements) of a 32-pixel grad_out row: 80 B, 16-byte aligned
+
+// Sum of S[i] over the `sub` (a power of two, wave-uniform) lanes of a group, up to 16 lanes = one DPP
+// row: quad_perm swaps (lane ^ 1, lane ^ 2), then row_half_mirror (lane i <-> 7 - i of its 8) and
+// row_mirror (i <-> 15 - i), which pair lanes that already hold equal quad / half-row sums.
+// ONE asm statement with scalar branches on `sub` inside: hipcc lowers the DPP builtin to mov +
+// mov_dpp + add, and separate conditional statements cost a register copy per value and level;
+// the s_nops cover the VALU-write -> DPP-read hazard (2 wait states), not padded for inline asm.
+#define HP_DPP_LVL(MOD)                                                                           \
+      "v_add_f32_dpp %0, %0, %0 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
+      "v_add_f32_dpp %1, %1, %1 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
+      "v_add_f32_dpp %2, %2, %2 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
+      "v_add_f32_dpp %3, %3, %3 " MOD " row_mask:0xf bank_mask:0xf\n\t"                           \
+      "s_nop 1\n\t"
+template <int NC> __device__ __forceinline__ void hp_dpp_sum(float (&S)[NC], int sub) {
+#pragma unroll
+  for (int o = 0; o < NC; o += 4)
+    asm("s_nop 1\n\t"
+        "s_cmp_lt_i32 %4, 2\n\t"
+        "s_cbranch_scc1 Ldpp_end%=\n\t"
+        HP_DPP_LVL("quad_perm:[1,0,3,2]")
+        "s_cmp_lt_i32 %4, 4\n\t"
+        "s_cbranch_scc1 Ldpp_end%=\n\t"
+        HP_DPP_LVL("quad_perm:[2,3,0,1]")
+        "s_cmp_lt_i32 %4, 8\n\t"
+        "s_cbranch_scc1 Ldpp_end%=\n\t"
+        HP_DPP_LVL("row_half_mirror")
+        "s_cmp_lt_i32 %4, 16\n\t"
+        "s_cbranch_scc1 Ldpp_end%=\n\t"
+        HP_DPP_LVL("row_mirror")
+        "Ldpp_end%=:"
+        : "+v"(S[o]), "+v"(S[o + 1]), "+v"(S[o + 2]), "+v"(S[o + 3])
+        : "s"(sub)
+        : "scc");
+}
+#undef HP_DPP_LVL
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// 8 consecutive K values of this lane's matrix column from a row-major [K][N] LDS tile: two
+// ds_read_b64_tr_b16 (4 rows each, `step` elements apart); `p` = this lane's piece of the block
+template <typename Raw> __device__ __forceinline__ void lds_tr2(const Raw *p, int step, U4 &out) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + step));
+  struct P { s16x4 a, b; } pk = {a, b};
+  out = __builtin_bit_cast(U4, pk);
+}
 
 // ---- dimensions / workspace of the 16-bit path ----
 struct HpDims {

@@ -24,17 +24,6 @@ namespace mdconv {
 
 namespace {
 
-constexpr int kPP = 40;   // LDS pitch (16-bit elements) of a 32-pixel grad_out row: 80 B
-
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-template <typename Raw> __device__ __forceinline__ void lds_tr2(const Raw *p, int step, U4 &out) {
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + step));
-  struct P { s16x4 a, b; } pk = {a, b};
-  out = __builtin_bit_cast(U4, pk);
-}
-
 template <typename T, int WAVES, int MB2>
 __global__ __launch_bounds__(64 * WAVES) void hp_gemm2_kernel(
     Geom g, HpDims hd, const int4 *__restrict__ btab, const typename T::Raw *__restrict__ gout,

@@ -1,10 +1,11 @@
 // hp_host.hip -- dispatch, workspace layout and kernel sequence of the native 16-bit path.
 //
 // forward : pack weights -> channels-last input copy -> hp_fwd_kernel
-// backward: pack W^T -> channels-last input copy -> hp_bwd2_kernel (GEMM-1 + coordinate gradients +
+// backward: pack W^T -> channels-last input copy -> hp_bwd3_kernel (GEMM-1 + coordinate gradients +
 //           grad_col rows + column rows with ONE gather pass, CSR counting) -> hp_gemm2_kernel (dense
-//           GEMM-2 over the column rows) -> split-K reduce of grad_weight, grad_bias ->
-//           [weights-ready event] -> CSR scan + fill -> col2im gather
+//           GEMM-2 over the column rows)   [shapes outside hp_bwd3: hp_bwd2_kernel, GEMM-2 fused in]
+//           -> split-K reduce of grad_weight, grad_bias -> [weights-ready event] -> CSR scan + fill ->
+//           col2im gather
 // Calls whose channels-last copy would exceed 2 GiB (32-bit buffer offsets) are cut into batch
 // chunks; grad_weight accumulates across chunks.
 #include "hp_kernels.hpp"
@@ -47,6 +48,14 @@ Geom chunk_geom(const Geom &g, int bc) {
   return c;
 }
 
+// which backward kernel: MDCONV_HP_BWD = 1 -> hp_bwd (lane = pixel), 2 -> hp_bwd2 (fused, tap-stationary),
+// 3 (default) -> hp_bwd3 + hp_gemm2 where the shape qualifies, else as 2
+int bwd_version() {
+  static const int v = getenv("MDCONV_HP_BWD") ? atoi(getenv("MDCONV_HP_BWD")) : 3;
+  return v;
+}
+bool use_bwd3(const Geom &g, const HpDims &hd) { return bwd_version() >= 3 && hp_bwd3_supported(g, hd); }
+
 struct FwdLayout { size_t off_xt, off_w, off_tab, total; };
 struct BwdLayout { size_t off_xt, off_w, off_tab, off_gcol, off_col, off_part, off_gw32, off_cnt, off_rowptr, off_entries, total; };
 
@@ -79,7 +88,7 @@ BwdLayout bwd_layout(const Geom &gc, const HpDims &hd) {
   L.off_w = off;    off += align_up((size_t)gc.K * hd.cblks * hd.nks * 1024);
   L.off_tab = off;  off += align_up((size_t)hd.cblks * sizeof(int4));
   L.off_gcol = off; off += align_up((size_t)gc.B * gc.K * gc.S_o * hd.Cp * 2);
-  L.off_col = off;  off += kHpFuse2 ? 0 : align_up((size_t)gc.B * gc.K * gc.S_o * hd.Cp * 2);   // column rows for GEMM-2
+  L.off_col = off;  off += use_bwd3(gc, hd) ? align_up((size_t)gc.B * gc.K * gc.S_o * hd.Cp * 2) : 0;   // column rows for GEMM-2
   // a shorter last chunk can have MORE ranges than a full one (ranges is not monotonic in the tile
   // count), so the partials are sized for the bound; gw32 = running fp32 grad_weight over chunks
   L.off_part = off; off += align_up((size_t)gc.K * hd.max_ranges * hd.cblks * hd.MB2 * 4096);
@@ -269,27 +278,29 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
     if (g.in_cl) xt = (const char *)t.input + (size_t)b0 * g.S_i * g.C * 2;   // already channels-last
     else if ((rc = hp_nchw_to_nhwc(gc, hd, tc.input, base + L.off_xt, stream))) return rc;
     if ((rc = hp_csr_zero(gc, cnt, stream))) return rc;
-    static const int bwd_ver = getenv("MDCONV_HP_BWD") ? atoi(getenv("MDCONV_HP_BWD")) : 2;
-    const bool bwd2 = bwd_ver == 2 && g.DG <= 4 && hp_bwd2_lds_bytes(gc, hd) <= 160 * 1024;
-    profile_mark(1, true, stream, bwd2 ? "hp_bwd2_kernel" : "hp_bwd_kernel");
-    if (bwd2)
+    const bool bwd3 = use_bwd3(gc, hd);
+    const bool bwd2 = !bwd3 && bwd_version() >= 2 && g.DG <= 4 && hp_bwd2_lds_bytes(gc, hd) <= 160 * 1024;
+    profile_mark(1, true, stream, bwd3 ? "hp_bwd3_kernel" : (bwd2 ? "hp_bwd2_kernel" : "hp_bwd_kernel"));
+    if (bwd3)
+      rc = hp_backward3_launch(gc, hd, dtype, tc, xt, base + L.off_w, base + L.off_gcol, base + L.off_col, cnt, stream);
+    else if (bwd2)
       rc = hp_backward2_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                                (const int4 *)(base + L.off_tab), base + L.off_gcol,
-                               base + L.off_col, (float *)(base + L.off_part), cnt, stream);
+                               (float *)(base + L.off_part), cnt, stream);
     else
       rc = hp_backward_launch(gc, hd, dtype, tc, xt, base + L.off_w,
                               (const int4 *)(base + L.off_tab), base + L.off_gcol,
                               (float *)(base + L.off_part), cnt, stream);
     profile_mark(1, false, stream);
     if (rc) return rc;
-    if (bwd2 && !kHpFuse2) {
+    if (bwd3) {
       profile_mark(2, true, stream, "hp_gemm2_kernel");
       rc = hp_gemm2_launch(gc, hd, dtype, tc, (const int4 *)(base + L.off_tab), base + L.off_col,
                            (float *)(base + L.off_part), stream);
       profile_mark(2, false, stream);
       if (rc) return rc;
     }
-    if ((rc = hp_reduce_grad_weight(gc, hd, bwd2 && !kHpFuse2 ? hd.ranges_w : hd.ranges, dtype, (const float *)(base + L.off_part),
+    if ((rc = hp_reduce_grad_weight(gc, hd, bwd3 ? hd.ranges_w : hd.ranges, dtype, (const float *)(base + L.off_part),
                                     (const int4 *)(base + L.off_tab), t.grad_weight,
                                     multi ? (float *)(base + L.off_gw32) : nullptr, first, last, stream)))
       return rc;

@@ -38,12 +38,18 @@ int hp_backward_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors
                        const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                        hipStream_t stream);
 
-// hp_bwd2.hip: GEMM-1 + coordinate gradients + grad_col rows + column rows with line-wide gathers
-// (thread roles change between phases); GEMM-2 is hp_gemm2.hip
+// hp_bwd2.hip: the same kernel with line-wide gathers (thread roles change between phases)
 size_t hp_bwd2_lds_bytes(const Geom &g, const HpDims &hd);
 int hp_backward2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
-                        const void *wpb, const int4 *btab, void *gcol, void *colbuf, float *part, int *cnt,
+                        const void *wpb, const int4 *btab, void *gcol, float *part, int *cnt,
                         hipStream_t stream);
+
+// hp_bwd3.hip: pixel-stationary GEMM-1 + coordinate gradients + grad_col rows + column rows (GEMM-2 is
+// hp_gemm2.hip); one conv group, one deformable group, Cp a power of two
+bool hp_bwd3_supported(const Geom &g, const HpDims &hd);
+size_t hp_bwd3_lds_bytes(const HpDims &hd);
+int hp_backward3_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
+                        const void *wpb, void *gcol, void *colbuf, int *cnt, hipStream_t stream);
 
 // hp_gemm2.hip: grad_W partials = grad_out . col^T over the column rows, dense, split over pixel ranges
 size_t hp_gemm2_lds_bytes(const HpDims &hd);

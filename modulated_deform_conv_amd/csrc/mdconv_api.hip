@@ -265,6 +265,11 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
   }
   g_last_path = MDCONV_PATH_DIRECT;
   g_last_kernels = MDCONV_KERNELS_DIRECT;
+  if (d->dtype == MDCONV_F16 || d->dtype == MDCONV_BF16) {
+    if ((rc = check_ws(ws, ws_bytes, direct16_workspace_bytes(g)))) return rc;
+    if ((rc = direct16_backward(g, d->dtype, t, ws, s))) return rc;
+    return record_weight_ready(s);
+  }
   if (!g_accumulate) {
     // the direct kernels scatter with atomics, so "overwrite" means: clear first
     const size_t es = d->dtype == MDCONV_F64 ? 8 : (d->dtype == MDCONV_F32 ? 4 : 2);
@@ -357,9 +362,11 @@ int mdconv_out_size(const mdconv_desc *d, int axis) {
 size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward) {
   Geom g;
   if (fill_geom(d, &g)) return 0;
-  if (current_path() == MDCONV_PATH_DIRECT) return 0;
+  const bool half = d->dtype == MDCONV_F16 || d->dtype == MDCONV_BF16;
+  const size_t direct = backward && half ? direct16_workspace_bytes(g) : 0;   // fp32 copies for the scatter kernels
+  if (current_path() == MDCONV_PATH_DIRECT) return direct;
   if (hp_supported(g, d->dtype, backward != 0)) return hp_workspace_bytes(g, d->dtype, backward != 0);
-  if (!mfma_supported(g, d->dtype, backward != 0)) return 0;
+  if (!mfma_supported(g, d->dtype, backward != 0)) return direct;
   return mfma_workspace_bytes(g, d->dtype, backward != 0);
 }
 

@@ -407,6 +407,57 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// 16-bit tensors on the shape-generic backward: it scatters grad_input / grad_weight with atomics,
+// and a 16-bit atomic rounds at EVERY add (bf16: 2^-9 each).  So the call runs on fp32 copies in
+// the workspace -- fresh, zeroed gradient buffers -- and each gradient is rounded once on the way out.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct D16Plan { size_t off_x, off_off, off_m, off_w, off_go, off_gi, off_goff, off_gm, off_gw, off_gb, total; };
+D16Plan direct16_plan(const Geom &g) {
+  D16Plan p;
+  size_t off = 0;
+  auto take = [&](size_t &slot, size_t elems) { slot = off; off += align_up(elems * sizeof(float)); };
+  const size_t n_x = (size_t)g.B * g.C * g.S_i, n_off = (size_t)g.B * g.DG * g.nd * g.K * g.S_o;
+  const size_t n_m = (size_t)g.B * g.DG * g.K * g.S_o, n_w = (size_t)g.O * g.Cg * g.K, n_go = (size_t)g.B * g.O * g.S_o;
+  take(p.off_x, n_x); take(p.off_off, n_off); take(p.off_m, n_m); take(p.off_w, n_w); take(p.off_go, n_go);
+  take(p.off_gi, n_x); take(p.off_goff, n_off); take(p.off_gm, n_m); take(p.off_gw, n_w); take(p.off_gb, g.O);
+  p.total = off;
+  return p;
+}
+}  // namespace
+
+size_t direct16_workspace_bytes(const Geom &g) { return direct16_plan(g).total; }
+
+int direct16_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  const D16Plan p = direct16_plan(g);
+  char *base = (char *)ws;
+  const int64_t n_x = (int64_t)g.B * g.C * g.S_i, n_off = (int64_t)g.B * g.DG * g.nd * g.K * g.S_o;
+  const int64_t n_m = (int64_t)g.B * g.DG * g.K * g.S_o, n_w = (int64_t)g.O * g.Cg * g.K, n_go = (int64_t)g.B * g.O * g.S_o;
+  int rc;
+  if ((rc = widen(dtype, t.input, (float *)(base + p.off_x), n_x, stream))) return rc;
+  if ((rc = widen(dtype, t.offset, (float *)(base + p.off_off), n_off, stream))) return rc;
+  if (t.mask && (rc = widen(dtype, t.mask, (float *)(base + p.off_m), n_m, stream))) return rc;
+  if ((rc = widen(dtype, t.weight, (float *)(base + p.off_w), n_w, stream))) return rc;
+  if ((rc = widen(dtype, t.grad_output, (float *)(base + p.off_go), n_go, stream))) return rc;
+  if ((rc = zero_bytes(base + p.off_gi, p.total - p.off_gi, stream))) return rc;   // the five gradient buffers are contiguous
+  Tensors tc = t;
+  tc.input = base + p.off_x; tc.offset = base + p.off_off; tc.mask = t.mask ? base + p.off_m : nullptr;
+  tc.weight = base + p.off_w; tc.grad_output = base + p.off_go;
+  tc.grad_input = base + p.off_gi; tc.grad_offset = base + p.off_goff;
+  tc.grad_mask = t.grad_mask ? base + p.off_gm : nullptr;
+  tc.grad_weight = base + p.off_gw; tc.grad_bias = base + p.off_gb;
+  Geom gc = g;
+  gc.acc_data = gc.acc_w = 1;   // the kernels add into the zeroed fp32 buffers
+  if ((rc = direct_backward(gc, MDCONV_F32, tc, stream))) return rc;
+  if ((rc = narrow(dtype, (const float *)tc.grad_input, t.grad_input, n_x, g.acc_data != 0, stream))) return rc;
+  if ((rc = narrow(dtype, (const float *)tc.grad_offset, t.grad_offset, n_off, g.acc_data != 0, stream))) return rc;
+  if (t.grad_mask && (rc = narrow(dtype, (const float *)tc.grad_mask, t.grad_mask, n_m, g.acc_data != 0, stream))) return rc;
+  if ((rc = narrow(dtype, (const float *)tc.grad_weight, t.grad_weight, n_w, g.acc_w != 0, stream))) return rc;
+  if (g.with_bias && (rc = narrow(dtype, (const float *)tc.grad_bias, t.grad_bias, g.O, g.acc_w != 0, stream))) return rc;
+  return MDCONV_OK;
+}
+
 bool mfma_supported(const Geom &g, int dtype, bool backward) {
   if (dtype != MDCONV_F32 && dtype != MDCONV_F16 && dtype != MDCONV_BF16) return false;
   if (g.in_sz[g.nd - 1] < 2) return false;   // paired-corner gathers need 2 columns

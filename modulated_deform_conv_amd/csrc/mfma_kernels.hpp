@@ -9,6 +9,10 @@ size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward);
 int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
 int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
 
+// 16-bit tensors on the shape-generic backward kernels: fp32 copies in the workspace, one rounding per gradient
+size_t direct16_workspace_bytes(const Geom &g);
+int direct16_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
+
 // records the calling thread's "grad_weight / grad_bias are final" event on `stream`
 // (include/mdconv.h: mdconv_stream_wait_weight_ready)
 int record_weight_ready(hipStream_t stream);

@@ -198,12 +198,17 @@ def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
                    "reads it (mdeformable_conv.cu:9-34); masking the values costs a VALU select per loaded "
                    "element inside the MFMA-bound K loops")
 def test_fp32_non_finite_border_pixel_is_not_read(path):
-    """The 16-bit twin of this test (tests/test_gpu_hp.py) passes: those kernels park invalid
-    corners out of the buffer's range."""
-    case = CASE_BY_NAME["mfma_mdcn2d_c32_o48_9x10"]
+    """1x1 kernel, x-offset -0.5 everywhere: output column 0 samples between columns -1 (outside, never
+    read by the reference) and 0; the fp32 kernels fetch the pair (column 0, column 1) and give column 1
+    the weight 0.  With Inf in input column 1 the reference's column 0 stays finite.  The 16-bit twin of
+    this test (tests/test_gpu_hp.py) passes: those kernels park invalid corners out of the buffer's range."""
+    case = CASE_BY_NAME["mfma_mdcn2d_k1_c64_o32"]
     t = make_inputs(case, dtype=torch.float32, device="cuda")
     t["offset"].zero_()
-    t["input"][0, :, 0, 1] = float("inf")     # reached as the unused pair element of column -1 / 0 samples
+    t["offset"][:, 0] = 0.25
+    t["offset"][:, 1] = -0.5
+    t["input"][0, :, :, 1] = float("inf")
     out, _, _ = run_product(case, t, path)
     want_out, _ = run_oracle(case, t, torch.float32)
+    assert torch.isfinite(want_out[0, :, :, 0]).all() and not torch.isfinite(want_out[0, :, :, 1]).any()
     assert torch.equal(torch.isfinite(out.cpu()), torch.isfinite(want_out))

@@ -1,12 +1,8 @@
 mkdir -p gpurun_out
-SPLIT=$PWD/modulated_deform_conv_amd/libmdconv_hip_split.so
-(timeout 600 python -m pytest tests/test_gpu_hp.py -m gpu -x -q 2>&1 | tail -5) > gpurun_out/t3_fused_brick.log 2>&1
-(MDCONV_LIB=$SPLIT timeout 600 python -m pytest tests/test_gpu_hp.py -m gpu -x -q 2>&1 | tail -5) > gpurun_out/t3_split_brick.log 2>&1
-for v in fused split; do for br in 1 0; do
-  L=""; [ $v = split ] && L=$SPLIT
-  echo "== $v brick=$br" >> gpurun_out/b3.txt
-  MDCONV_LIB=$L MDCONV_HP_BRICK=$br python tools/bench_configs.py cfg3 cfg5 >> gpurun_out/b3.txt 2>&1
-  MDCONV_LIB=$L MDCONV_HP_BRICK=$br python - >> gpurun_out/b3.txt 2>&1 <<'PY'
+(timeout 900 python -m pytest tests/test_gpu_hp.py tests/test_gpu_hp_forced.py "tests/test_gpu_parity.py::test_fp32_non_finite_border_pixel_is_not_read" -m gpu -q 2>&1 | tail -40) > gpurun_out/t5.log 2>&1
+(timeout 600 python -m pytest tests/test_gpu_fullshape_oracle.py -m gpu -q -k "cfg5 or cfg3" 2>&1 | tail -15) > gpurun_out/t5b.log 2>&1
+python tools/bench_configs.py cfg5 cfg3 > gpurun_out/b5.txt 2>&1
+python - >> gpurun_out/b5.txt 2>&1 <<'PY'
 import sys, torch
 sys.path.insert(0, ".")
 import bench
@@ -14,5 +10,5 @@ for n in ("cfg3", "cfg5"):
     r = bench.time_other_config(n, "cuda")
     print(n, r["fwd_ms"], r["bwd_ms"], r["kernels_ms"])
 PY
-done; done
-tail -3 gpurun_out/t3_fused_brick.log gpurun_out/t3_split_brick.log; cat gpurun_out/b3.txt
+MDCONV_HP_BWD=2 python tools/bench_configs.py cfg5 >> gpurun_out/b5.txt 2>&1
+tail -12 gpurun_out/t5.log; tail -5 gpurun_out/t5b.log; cat gpurun_out/b5.txt
