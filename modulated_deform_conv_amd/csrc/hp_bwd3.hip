@@ -67,16 +67,18 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
   int *St = reinterpret_cast<int *>(mine + REGION);                        // [32][SW]
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int n0 = tile * 128 + wave * 32;            // first pixel of this wave (wave-uniform)
-  const bool wave_live = n0 < g.N;
-  const int b0 = wave_live ? n0 / g.S_o : 0, p0 = n0 - b0 * g.S_o;
+  // first pixel of this wave's 32-pixel segment (wave-uniform; hp_common.hpp: linear or blocked tile order)
+  int b0, p0;
+  hp_wave_segment(g, hd.blocked, tile, wave, b0, p0);
+  const bool wave_live = b0 < g.B;
+  if (!wave_live) { b0 = 0; p0 = 0; }
   const bool one_img = p0 + 31 < g.S_o;             // all 32 pixels in image b0: scalar row bases, buffer stores
 
   // ---- the pixel this lane owns in the state role (lanes 32-63 mirror 0-31) ----
-  const int n_raw = n0 + pl;
-  const bool live = n_raw < g.N;
-  const int n = live ? n_raw : g.N - 1;
-  const int b = n / g.S_o, pix = n - b * g.S_o;
+  int b = b0, pix = p0 + pl;
+  while (pix >= g.S_o) { pix -= g.S_o; ++b; }
+  const bool live = wave_live && b < g.B;
+  if (!live) { b = g.B - 1; pix = g.S_o - 1; }
   int oc[ND];
   out_coords<ND>(g, pix, oc);
 
@@ -211,42 +213,46 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
 
   // ---- gather role ----
   const int gp = lane / LPP, oc8 = lane % LPP;
-  struct Set { U4 x[NC]; float w[NC]; U4 gq; int grow, img; };
+  // a Set holds only the gathered corner octets; weights, row offset and the grad_col piece are re-read
+  // from LDS when the set is consumed (28 registers less per wave: two sets in flight fit without spills)
+  struct Set { U4 x[NC]; };
   auto issue = [&](Set &s, int it) {
-    const int p = it * PPI + gp;
-    const int *sp = St + p * SW;
-    int ev[SW];
+    const int *sp = St + (it * PPI + gp) * SW;
+    int ev[NC];
 #pragma unroll
-    for (int q = 0; q < SW; q += 4) {
+    for (int q = 0; q < NC; q += 4) {
       const int4 e = *reinterpret_cast<const int4 *>(sp + q);
       ev[q] = e.x; ev[q + 1] = e.y; ev[q + 2] = e.z; ev[q + 3] = e.w;
     }
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {
-      s.x[ci] = buf_load4u(r_xt, ev[ci] + oc8 * 16, 0);
-      s.w[ci] = __int_as_float(ev[NC + ci]);
-    }
-    s.grow = ev[2 * NC];
-    s.img = ev[2 * NC + 1];
-    s.gq = *reinterpret_cast<const U4 *>(Gc + p * pitch + oc8 * 8);
+    for (int ci = 0; ci < NC; ++ci) s.x[ci] = buf_load4u(r_xt, ev[ci] + oc8 * 16, 0);
   };
   auto consume = [&](const Set &s, int it) {
     const int p = it * PPI + gp;
+    int *sp = St + p * SW;
+    float w[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q += 4) {
+      const int4 e = *reinterpret_cast<const int4 *>(sp + NC + q);
+      w[q] = __int_as_float(e.x); w[q + 1] = __int_as_float(e.y); w[q + 2] = __int_as_float(e.z); w[q + 3] = __int_as_float(e.w);
+    }
+    const int4 tail = *reinterpret_cast<const int4 *>(sp + 2 * NC);   // (grad_col row offset, image, -, -)
+    const U4 gq = *reinterpret_cast<const U4 *>(Gc + p * pitch + oc8 * 8);
     float col[8], S[NC];
 #pragma unroll
     for (int j = 0; j < 8; ++j) col[j] = 0.f;
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) {
-      S[ci] = dot8<T>(0.f, s.x[ci], s.gq);
-      mac8<T>(col, s.x[ci], s.w[ci]);
+      S[ci] = dot8<T>(0.f, s.x[ci], gq);
+      mac8<T>(col, s.x[ci], w[ci]);
     }
     const U4 cq = pack8<T>(col);
     if (one_img) {   // scalar row base, dead pixels out of range (dropped)
-      buf_store4u(r_gcol, s.grow + oc8 * 16, 0, s.gq);
-      buf_store4u(r_col, s.grow + oc8 * 16, 0, cq);
-    } else if (s.grow != kHpOob) {
-      const size_t e = (size_t)s.img * gcol_img + (s.grow >> 1) + oc8 * 8;
-      *reinterpret_cast<U4 *>(gcol + e) = s.gq;
+      buf_store4u(r_gcol, tail.x + oc8 * 16, 0, gq);
+      buf_store4u(r_col, tail.x + oc8 * 16, 0, cq);
+    } else if (tail.x != kHpOob) {
+      const size_t e = (size_t)tail.y * gcol_img + (tail.x >> 1) + oc8 * 8;
+      *reinterpret_cast<U4 *>(gcol + e) = gq;
       *reinterpret_cast<U4 *>(colbuf + e) = cq;
     }
     // S summed over the pixel's LPP lanes: DPP adds inside a row of 16, ds_bpermute beyond
@@ -256,7 +262,6 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
       for (int ci = 0; ci < NC; ++ci) S[ci] += __shfl_xor(S[ci], 16, 64);
     }
     if (oc8 == 0) {   // the row's corner offsets are dead by now: S takes their place
-      int *sp = St + p * SW;
 #pragma unroll
       for (int q = 0; q < NC; q += 4)
         *reinterpret_cast<int4 *>(sp + q) = make_int4(__float_as_int(S[q]), __float_as_int(S[q + 1]),
@@ -288,20 +293,23 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     }
     __syncthreads();   // B1: every wave is done with this tap's W^T slab
     // ---- gather phase (+ the next tap's W^T slab, WPI pieces per iteration) ----
-    const U4 *wnext = wpb + (size_t)(tap + 1) * WTOT;
+    // piece k of iteration `it`: element tid + (it * WPI + k) * 256 of the slab, loaded at the top of the
+    // iteration (unconditionally, from a clamped index: a conditional load into a struct ended up in scratch)
+    // and stored to LDS at its end
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const bool stage = tap + 1 < g.K;
+    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(wpb + (size_t)(stage ? tap + 1 : tap) * WTOT);
+    u32x4 *wdst = reinterpret_cast<u32x4 *>(Ws);
     Set sa, sb;
-    // piece k of iteration `it`: element tid + (it * WPI + k) * 256 of the slab (loaded at the top of the
-    // iteration, stored to LDS at its end; plain values, no arrays: hipcc put a `wr[]` array in scratch)
-    auto w_idx = [&](int it, int k) { return tid + (it * WPI + k) * 256; };
-    auto w_on = [&](int it, int k) { return stage && it * WPI + k < WPT && w_idx(it, k) < WTOT; };
     if (wave_live) issue(sa, 0);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      U4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
       static_assert(WPI <= 2, "W^T pieces per gather iteration");
-      if (w_on(it, 0)) w0 = wnext[w_idx(it, 0)];
-      if (WPI > 1 && w_on(it, 1)) w1 = wnext[w_idx(it, 1)];
+      const int i0 = tid + (it * WPI) * 256, i1 = i0 + 256;
+      const bool on0 = stage && it * WPI < WPT && i0 < WTOT;
+      const bool on1 = WPI > 1 && stage && it * WPI + 1 < WPT && i1 < WTOT;
+      const u32x4 w0 = wsrc[on0 ? i0 : 0];
+      const u32x4 w1 = wsrc[on1 ? i1 : 0];
       if (wave_live) {
         if (it & 1) {
           if (it + 1 < NIT) issue(sa, it + 1);
@@ -311,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
           consume(sa, it);
         }
       }
-      if (w_on(it, 0)) Ws[w_idx(it, 0)] = w0;
-      if (WPI > 1 && w_on(it, 1)) Ws[w_idx(it, 1)] = w1;
+      if (on0) wdst[i0] = w0;
+      if (on1) wdst[i1] = w1;
     }
     if (wave_live) finish(tap);
     __syncthreads();   // B2: the next tap's W^T slab is complete

@@ -231,6 +231,163 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-pass gather (round 3): every grad_col row and every list entry is read ONCE.
+// The one-pass kernel above visits, per target, the 2^(ND-1) anchor rows that reach it, so a sample's
+// row is fetched 2^(ND-1) times -- and at the 3-D shards those repeats are 32 workgroups apart: 14 GB of
+// HBM reads for 3.6 GB of rows at cfg5 (L2 hit 14 %, 7 TB/s: HBM-bound, profiles/r02_hp_counters.md).
+// Pass 1 walks ANCHOR rows instead and keeps, per anchor column, one partial sum for each of the
+// 2^(ND-1) target rows the anchor row feeds (s: bit a set = the target one lower on outer axis a, i.e.
+// weight rl_a; clear = weight rh_a) -- the same multiply-adds as before, spread over NS accumulators --
+// and writes them as 16-bit rows A[segment][anchor][s][channels].  Pass 2 is a 2^(ND-1)-point stencil
+// over A (target t takes s from anchor row t + s) plus the transpose to [B, C, S_i].
+// ---------------------------------------------------------------------------------------------
+constexpr int kRunA = 16;   // anchors per run: the carry-in anchor is read twice (1 / 16 of the rows)
+
+template <int ND, typename T, int LPD>
+__global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, int S_e,
+                                                             const typename T::Raw *__restrict__ gcol,
+                                                             const int *__restrict__ rowptr,
+                                                             const int4 *__restrict__ entries,
+                                                             typename T::Raw *__restrict__ sums) {
+  using Raw = typename T::Raw;
+  constexpr int L = ND - 1, NS = 1 << L;
+  constexpr int NQ = 64 / LPD, RUNS = 4 * NQ;
+  constexpr int UB = LPD < 4 ? LPD : 4;    // row loads in flight per step
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane / LPD, r = lane % LPD;
+  const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;   // channels that share one list
+  const int runs_per_seg = (S_e + kRunA - 1) / kRunA;
+  const int blocks_per_seg = (runs_per_seg + RUNS - 1) / RUNS;
+  const int seg = blockIdx.x / blocks_per_seg;                  // b * DG + dg
+  const int run = (blockIdx.x - seg * blocks_per_seg) * RUNS + wave * NQ + j;
+  const int b = seg / g.DG, dg = seg - b * g.DG;
+  const int a_lo = run * kRunA;                                 // first anchor of this run
+  if (a_lo >= S_e) return;
+  const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * hd.Cp, (size_t)g.K * g.S_o * hd.Cp * 2);
+  const int *rp = rowptr + (int64_t)seg * (S_e + 1);
+  const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * 2;
+  const bool chan_on = r * 8 < cseg;
+  const int c_voff = chan_on ? (dg * cseg + r * 8) * 2 : kHpOob;
+  Raw *out = sums + ((int64_t)seg * S_e * NS) * cseg + r * 8;
+  float cur[NS][8], nxt[NS][8];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cur[s][k] = nxt[s][k] = 0.f;
+  for (int step = 0; step <= kRunA; ++step) {
+    const int ea = a_lo - 1 + step;
+    const bool on = ea >= 0 && ea < S_e;
+    const int e0 = on ? rp[ea] : 0, e1 = on ? rp[ea + 1] : 0;
+    for (int base = e0; __any(base < e1); base += LPD) {
+      const int cnt = max(0, min(LPD, e1 - base));
+      int src_m = 0;
+      float wx_m = 0.f, wy_m = 0.f, f0l = 0.f, f0h = 0.f, f1l = 0.f, f1h = 0.f;   // weights 0, row 0 beyond the list
+      if (r < cnt) {
+        const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
+        src_m = ea4.x;
+        wx_m = __int_as_float(ea4.y); wy_m = __int_as_float(ea4.z);
+        f0l = __int_as_float(ea4.w); f0h = __int_as_float(eb4.x);
+        f1l = __int_as_float(eb4.y); f1h = __int_as_float(eb4.z);
+      }
+      // per-row factors of the NS sums: first outer axis (rl, rh) x (3-D) second outer axis
+      float fa_m[NS];
+      if constexpr (ND == 2) { fa_m[0] = f0h; fa_m[1] = f0l; }
+      else { fa_m[0] = f0h * f1h; fa_m[1] = f0h * f1l; fa_m[2] = f0l * f1h; fa_m[3] = f0l * f1l; }
+#pragma unroll 1
+      for (int u0 = 0; u0 < LPD; u0 += UB) {
+        if (!__any(u0 < cnt)) break;   // (wave-uniform) no run of this wave has entries left in the batch
+        {
+          U4 v[UB];
+          float wx[UB], wy[UB], fa[UB][NS];
+#pragma unroll
+          for (int k = 0; k < UB; ++k) {
+            const int src = __shfl(src_m, u0 + k, LPD);
+            wx[k] = __shfl(wx_m, u0 + k, LPD);
+            wy[k] = __shfl(wy_m, u0 + k, LPD);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) fa[k][s] = __shfl(fa_m[s], u0 + k, LPD);
+            v[k] = buf_load4u(r_gc, src * hd.Cp * 2 + c_voff, 0);
+          }
+#pragma unroll
+          for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              mac8<T>(cur[s], v[k], fa[k][s] * wx[k]);
+              mac8<T>(nxt[s], v[k], fa[k][s] * wy[k]);
+            }
+        }
+      }
+    }
+    if (step > 0 && on && chan_on) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        *reinterpret_cast<U4 *>(out + ((int64_t)ea * NS + s) * cseg) = pack8<T>(cur[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { cur[s][k] = nxt[s][k]; nxt[s][k] = 0.f; }
+  }
+}
+
+// pass 2: grad_input[b][c][t] (+)= sum_s A[segment(b, c)][anchor row t + s][x][s][c]; workgroup = 64
+// consecutive targets x 64 channels, lanes = (target, channel octet), LDS transpose to [B, C, S_i]
+template <int ND, typename T>
+__global__ __launch_bounds__(256) void hp_col2im_combine_kernel(Geom g, HpDims hd, int S_e,
+                                                                const typename T::Raw *__restrict__ sums,
+                                                                typename T::Raw *__restrict__ grad_input) {
+  using Raw = typename T::Raw;
+  constexpr int L = ND - 1, NS = 1 << L;
+  constexpr int QT = 64, CW = 64, TP = QT + 2;
+  __shared__ Raw tile[CW * TP];
+  const int qtiles = (g.S_i + QT - 1) / QT;
+  const int b = blockIdx.x / qtiles, q0 = (blockIdx.x - b * qtiles) * QT;
+  const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;
+  const int W = g.in_sz[L];
+  for (int c0 = 0; c0 < hd.Cp; c0 += CW) {
+    // 8 lanes per target (64 channels), 32 targets per pass
+    for (int it = 0; it < QT / 32; ++it) {
+      const int ql = it * 32 + (threadIdx.x >> 3), q = q0 + ql;
+      const int c = c0 + (threadIdx.x & 7) * 8;
+      float acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      if (q < g.S_i && c < hd.Cp) {
+        const int dg = g.DG == 1 ? 0 : c / cseg;
+        const int cl = c - dg * cseg;
+        int tc[ND], rem = q;
+#pragma unroll
+        for (int a = L; a > 0; --a) { tc[a] = rem % g.in_sz[a]; rem /= g.in_sz[a]; }
+        tc[0] = rem;
+        const Raw *base = sums + ((int64_t)(b * g.DG + dg) * S_e * NS) * cseg + cl;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          int er = 0;
+#pragma unroll
+          for (int ax = 0; ax < L; ++ax) er = er * (g.in_sz[ax] + 1) + tc[ax] + ((s >> (L - 1 - ax)) & 1);
+          const U4 v = *reinterpret_cast<const U4 *>(base + (((int64_t)er * W + tc[L]) * NS + s) * cseg);
+          mac8<T>(acc, v, 1.f);
+        }
+      }
+      Raw *tp = tile + ((threadIdx.x & 7) * 8) * TP + ql;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) T::stf(tp + k * TP, acc[k]);
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < CW * QT; x += 256) {
+      const int cl = x / QT, ql = x - cl * QT;
+      const int c = c0 + cl, q = q0 + ql;
+      if (c < g.C && q < g.S_i) {
+        Raw *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q;
+        const float v = (float)tile[cl * TP + ql];
+        T::stf(dst, g.acc_data ? T::ldf(dst) + v : v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int ND, typename T>
 int launch_col2im(const Geom &g, const HpDims &hd, const Tensors &t, const void *gcol,
                   const int *rowptr, const void *entries, hipStream_t stream) {
@@ -284,6 +441,48 @@ int hp_csr_build(const Geom &g, int dtype, const Tensors &t, int *cnt, int *rowp
 #undef HP_CSR_T
 #undef HP_CSR
   return check_launch("hp_csr_fill");
+}
+
+template <int ND, typename T>
+static int launch_col2im2(const Geom &g, const HpDims &hd, const Tensors &t, const void *gcol, const int *rowptr,
+                   const void *entries, void *sums, hipStream_t stream) {
+  using Raw = typename T::Raw;
+  const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;
+  const int lanes = (cseg + 7) / 8;
+  const int S_e = hp_anchor_space(g);
+  const int runs_per_seg = (S_e + kRunA - 1) / kRunA;
+#define HP_C2S(LPD)                                                                              \
+  do {                                                                                           \
+    const int runs = 4 * (64 / LPD);                                                             \
+    hipLaunchKernelGGL((hp_col2im_sums_kernel<ND, T, LPD>),                                      \
+                       dim3(g.B * g.DG * ((runs_per_seg + runs - 1) / runs)), dim3(256), 0, stream, g, hd, S_e, \
+                       (const Raw *)gcol, rowptr, (const int4 *)entries, (Raw *)sums);           \
+  } while (0)
+  if (lanes <= 4) HP_C2S(4);
+  else if (lanes <= 8) HP_C2S(8);
+  else if (lanes <= 16) HP_C2S(16);
+  else if (lanes <= 32) HP_C2S(32);
+  else HP_C2S(64);
+#undef HP_C2S
+  int rc = check_launch("hp_col2im_sums");
+  if (rc) return rc;
+  hipLaunchKernelGGL((hp_col2im_combine_kernel<ND, T>), dim3(g.B * ((g.S_i + 63) / 64)), dim3(256), 0, stream, g, hd,
+                     S_e, (const Raw *)sums, (Raw *)t.grad_input);
+  return check_launch("hp_col2im_combine");
+}
+
+size_t hp_col2im_sums_bytes(const Geom &g, const HpDims &hd) {
+  const size_t cseg = g.DG == 1 ? hd.Cp : g.Cdg;
+  return (size_t)g.B * g.DG * hp_anchor_space(g) * (1 << (g.nd - 1)) * cseg * 2;
+}
+
+int hp_col2im2(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *gcol,
+               const int *rowptr, const void *entries, void *sums, hipStream_t stream) {
+  if (dtype == MDCONV_F16)
+    return g.nd == 2 ? launch_col2im2<2, F16>(g, hd, t, gcol, rowptr, entries, sums, stream)
+                     : launch_col2im2<3, F16>(g, hd, t, gcol, rowptr, entries, sums, stream);
+  return g.nd == 2 ? launch_col2im2<2, BF16>(g, hd, t, gcol, rowptr, entries, sums, stream)
+                   : launch_col2im2<3, BF16>(g, hd, t, gcol, rowptr, entries, sums, stream);
 }
 
 int hp_col2im(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *gcol,

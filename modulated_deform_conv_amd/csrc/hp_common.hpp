@@ -176,6 +176,41 @@ template <typename Raw> __device__ __forceinline__ void lds_tr2(const Raw *p, in
   out = __builtin_bit_cast(U4, pk);
 }
 
+// ---- tile order of the pixel-stationary kernels (hp_fwd2, hp_bwd3) ----
+// A workgroup owns 128 output pixels = 4 wave segments of 32.  With linear order the 64 workgroups an
+// XCD runs at a time (xcd_remap hands every XCD one contiguous run of tiles) cover two whole z-planes of
+// a 3-D image; the input rows they gather for ONE tap then span 4-5 planes -- more than the XCD's 4 MB
+// L2 at cfg5 (L2 hit 69 % forward, 65 % backward; a missing gather costs 4x the texture-path time of
+// a hit, tools/ubench_gather16.hip).  Blocked order (3-D, row length 32 / 64 / 128, 8 | rows): tiles are
+// numbered y-block of 8 rows slowest, then z, then the tiles of the 8 rows, so the same 64 workgroups
+// cover 8 rows x all z -- a compact slab whose per-tap footprint fits the L2.
+__host__ __device__ inline bool hp_blocked_ok(const Geom &g) {
+  if (g.nd != 3) return false;
+  const int W = g.out_sz[2];
+  return (W == 32 || W == 64 || W == 128) && g.out_sz[1] % 8 == 0;
+}
+// first pixel (inside image b) of wave segment `wave` of tile sequence number `s`; b >= g.B: beyond the batch
+__device__ __forceinline__ void hp_wave_segment(const Geom &g, int blocked, int s, int wave, int &b, int &pix0) {
+  if (!blocked) {
+    const int n0 = s * 128 + wave * 32;
+    b = n0 / g.S_o;
+    pix0 = n0 - b * g.S_o;
+    return;
+  }
+  const int W = g.out_sz[2], H = g.out_sz[1], Z = g.out_sz[0];
+  const int rt = 128 / W;               // rows per tile
+  const int tpb = 8 / rt;               // tiles per (y-block, z)
+  const int per_img = Z * (H / 8) * tpb;
+  b = s / per_img;
+  int r = s - b * per_img;
+  const int yb = r / (Z * tpb);
+  r -= yb * (Z * tpb);
+  const int z = r / tpb, yt = r - z * tpb;
+  const int seg = wave * 32;            // pixel offset inside the tile's rows
+  const int y = yb * 8 + yt * rt + seg / W, x = seg % W;
+  pix0 = (z * H + y) * W + x;
+}
+
 // ---- dimensions / workspace of the 16-bit path ----
 struct HpDims {
   int Cp;           // C_in rounded up to 32: channel pitch of xt and of the grad_col rows
@@ -197,6 +232,7 @@ struct HpDims {
   int tiles_per_range_w;
   int max_ranges;   // upper bound of ranges / ranges_w for ANY batch size of this geometry (workspace sizing)
   int ntiles;       // 32-pixel tiles
+  int blocked;      // pixel-stationary kernels: 1 = 128-pixel tiles in blocked order (hp_wave_segment), 0 = linear
 };
 
 }  // namespace mdconv

@@ -59,10 +59,20 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
   const int nvalid = min(MB, hd.oblks - orange * MB);       // real output-channel blocks of this row
 
   // ---- the pixel whose sampling state this lane computes (lanes 32-63 mirror 0-31) ----
-  const int n_raw = tile * 128 + wave * 32 + (lane & 31);
-  const bool live = n_raw < g.N;
-  const int n = live ? n_raw : g.N - 1;
-  const int b = n / g.S_o, pix = n - b * g.S_o;
+  int b, pix;
+  bool live;
+  if (hd.blocked) {   // tiles in blocked order (hp_common.hpp: hp_wave_segment): the segment never leaves its row
+    hp_wave_segment(g, 1, tile, wave, b, pix);
+    live = b < g.B;
+    pix = live ? pix + (lane & 31) : 0;
+    b = live ? b : g.B - 1;
+  } else {
+    const int n_raw = tile * 128 + wave * 32 + (lane & 31);
+    live = n_raw < g.N;
+    const int n = live ? n_raw : g.N - 1;
+    b = n / g.S_o;
+    pix = n - b * g.S_o;
+  }
   int oc[ND];
   out_coords<ND>(g, pix, oc);
 

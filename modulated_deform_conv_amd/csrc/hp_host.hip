@@ -57,7 +57,13 @@ int bwd_version() {
 bool use_bwd3(const Geom &g, const HpDims &hd) { return bwd_version() >= 3 && hp_bwd3_supported(g, hd); }
 
 struct FwdLayout { size_t off_xt, off_w, off_tab, total; };
-struct BwdLayout { size_t off_xt, off_w, off_tab, off_gcol, off_col, off_part, off_gw32, off_cnt, off_rowptr, off_entries, total; };
+struct BwdLayout { size_t off_xt, off_w, off_tab, off_gcol, off_col, off_part, off_gw32, off_cnt, off_rowptr, off_entries, off_sums, total; };
+
+// grad_input gather: MDCONV_HP_C2I = 1 -> one pass (every row read 2^(nd-1) times), 2 (default) -> two passes
+bool use_col2im2() {
+  static const int v = getenv("MDCONV_HP_C2I") ? atoi(getenv("MDCONV_HP_C2I")) : 2;
+  return v >= 2;
+}
 
 // images per chunk: channels-last input copy (and one image's grad_col) below the limit
 int chunk_batch(const Geom &g, const HpDims &hd, bool backward) {
@@ -98,6 +104,7 @@ BwdLayout bwd_layout(const Geom &gc, const HpDims &hd) {
   L.off_cnt = off;  off += align_up((size_t)gc.B * gc.DG * S_e * sizeof(int));
   L.off_rowptr = off; off += align_up((size_t)gc.B * gc.DG * (S_e + 1) * sizeof(int));
   L.off_entries = off; off += align_up((size_t)gc.B * gc.DG * gc.K * gc.S_o * 32);
+  L.off_sums = off; off += use_col2im2() ? align_up(hp_col2im_sums_bytes(gc, hd)) : 0;
   L.total = off;
   return L;
 }
@@ -155,6 +162,10 @@ HpDims hp_dims(const Geom &g) {
   hd.OpL = base_max + 32 * hd.MB2 > hd.Op ? base_max + 32 * hd.MB2 : hd.Op;
   hd.waves = pow2_ceil(hd.cblks);
   hd.ntiles = (g.N + 31) / 32;
+  {
+    static const int blocked_env = getenv("MDCONV_HP_BLOCKED") ? atoi(getenv("MDCONV_HP_BLOCKED")) : 1;
+    hd.blocked = blocked_env && hp_blocked_ok(g) ? 1 : 0;
+  }
   // pixel ranges per tap of the fused kernel: about one dispatch round of workgroups (2 workgroups of
   // 4 + 1 waves per CU, 1-2 of 8 + 2)
   const int slots = num_cus() * (hd.waves >= 8 ? hp_wg_per_cu8() : 2 * (4 / hd.waves));
@@ -306,8 +317,9 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
       return rc;
     if (b0 + bc >= g.B && (rc = record_weight_ready(stream))) return rc;
     if ((rc = hp_csr_build(gc, dtype, tc, cnt, rowptr, base + L.off_entries, stream))) return rc;
-    profile_mark(3, true, stream, "hp_col2im_kernel");
-    rc = hp_col2im(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, stream);
+    profile_mark(3, true, stream, use_col2im2() ? "hp_col2im_sums_kernel" : "hp_col2im_kernel");
+    rc = use_col2im2() ? hp_col2im2(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, base + L.off_sums, stream)
+                       : hp_col2im(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, stream);
     profile_mark(3, false, stream);
     if (rc) return rc;
   }

@@ -39,6 +39,9 @@ HP_CASES = [
     # line-wide backward, i.e. the lane = pixel kernel (hp_bwd.hip) is what runs
     _c("hp_mdcn2d_c256_o64_dg8", M2, 2, 256, 64, (9, 8), 3, dgroups=8, seed=117),
     _c("hp_dcn3d_c256_o32_dg8", D3, 1, 256, 32, (4, 5, 6), 3, dgroups=8, bias=False, seed=118),
+    # 3-D with rows of 32 / 64 pixels and 8 | rows: the blocked tile order of the pixel-stationary kernels
+    _c("hp_mdcn3d_c32_o32_rows32", M3, 2, 32, 32, (3, 16, 32), 3, seed=119),
+    _c("hp_dcn3d_c64_o32_rows64_dil2", D3, 1, 64, 32, (4, 8, 64), 3, padding=2, dilation=2, bias=False, seed=120),
 ]
 
 # 16-bit shapes the native kernels reject in at least one direction (hp_supported): more than 256

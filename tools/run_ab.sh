@@ -1,8 +1,10 @@
 mkdir -p gpurun_out
-(timeout 900 python -m pytest tests/test_gpu_hp.py tests/test_gpu_hp_forced.py "tests/test_gpu_parity.py::test_fp32_non_finite_border_pixel_is_not_read" -m gpu -q 2>&1 | tail -40) > gpurun_out/t5.log 2>&1
-(timeout 600 python -m pytest tests/test_gpu_fullshape_oracle.py -m gpu -q -k "cfg5 or cfg3" 2>&1 | tail -15) > gpurun_out/t5b.log 2>&1
-python tools/bench_configs.py cfg5 cfg3 > gpurun_out/b5.txt 2>&1
-python - >> gpurun_out/b5.txt 2>&1 <<'PY'
+(timeout 900 python -m pytest tests/test_gpu_hp.py tests/test_gpu_hp_forced.py -m gpu -q -x 2>&1 | tail -15) > gpurun_out/t7.log 2>&1
+(timeout 600 python -m pytest tests/test_gpu_fullshape_oracle.py -m gpu -q -k "cfg5 or cfg3" 2>&1 | tail -15) > gpurun_out/t7b.log 2>&1
+rm -f gpurun_out/b7.txt
+for m in 2 1; do
+echo "== C2I=$m" >> gpurun_out/b7.txt
+MDCONV_HP_C2I=$m python - >> gpurun_out/b7.txt 2>&1 <<'PY'
 import sys, torch
 sys.path.insert(0, ".")
 import bench
@@ -10,5 +12,6 @@ for n in ("cfg3", "cfg5"):
     r = bench.time_other_config(n, "cuda")
     print(n, r["fwd_ms"], r["bwd_ms"], r["kernels_ms"])
 PY
-MDCONV_HP_BWD=2 python tools/bench_configs.py cfg5 >> gpurun_out/b5.txt 2>&1
-tail -12 gpurun_out/t5.log; tail -5 gpurun_out/t5b.log; cat gpurun_out/b5.txt
+done
+bash tools/prof_cfg.sh cfg5 cfg3 >> gpurun_out/b7.txt 2>&1
+tail -4 gpurun_out/t7.log; tail -3 gpurun_out/t7b.log; cat gpurun_out/b7.txt
