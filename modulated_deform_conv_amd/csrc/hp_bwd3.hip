@@ -225,7 +225,13 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
       ev[q] = e.x; ev[q + 1] = e.y; ev[q + 2] = e.z; ev[q + 3] = e.w;
     }
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) s.x[ci] = buf_load4u(r_xt, ev[ci] + oc8 * 16, 0);
+    for (int ci = 0; ci < NC; ++ci) {
+#ifdef ABL_NOGATHER   // developer ablation (timing only): every corner from one cache-resident row
+      s.x[ci] = buf_load4u(r_xt, (ev[ci] & 0xff00) + oc8 * 16, 0);
+#else
+      s.x[ci] = buf_load4u(r_xt, ev[ci] + oc8 * 16, 0);
+#endif
+    }
   };
   auto consume = [&](const Set &s, int it) {
     const int p = it * PPI + gp;
@@ -238,15 +244,29 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     }
     const int4 tail = *reinterpret_cast<const int4 *>(sp + 2 * NC);   // (grad_col row offset, image, -, -)
     const U4 gq = *reinterpret_cast<const U4 *>(Gc + p * pitch + oc8 * 8);
-    float col[8], S[NC];
+    float S[NC];
+    U4 cq = {0, 0, 0, 0};
+    if constexpr (T::kPackedCol) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) col[j] = 0.f;
+      for (int ci = 0; ci < NC; ++ci) {
+        S[ci] = dot8<T>(0.f, s.x[ci], gq);
+        T::pk_mac8(cq, s.x[ci], w[ci]);
+      }
+    } else {
+      float col[8];
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {
-      S[ci] = dot8<T>(0.f, s.x[ci], gq);
-      mac8<T>(col, s.x[ci], w[ci]);
+      for (int j = 0; j < 8; ++j) col[j] = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        S[ci] = dot8<T>(0.f, s.x[ci], gq);
+        mac8<T>(col, s.x[ci], w[ci]);
+      }
+      cq = pack8<T>(col);
     }
-    const U4 cq = pack8<T>(col);
+#ifdef ABL_NOSTORE   // developer ablation (timing only): rows are (practically) never written
+    if (cq.x != 0x12345678u || gq.y != 0x9abcdef0u) {
+    } else
+#endif
     if (one_img) {   // scalar row base, dead pixels out of range (dropped)
       buf_store4u(r_gcol, tail.x + oc8 * 16, 0, gq);
       buf_store4u(r_col, tail.x + oc8 * 16, 0, cq);

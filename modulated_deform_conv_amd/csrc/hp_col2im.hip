@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
 // and writes them as 16-bit rows A[segment][anchor][s][channels].  Pass 2 is a 2^(ND-1)-point stencil
 // over A (target t takes s from anchor row t + s) plus the transpose to [B, C, S_i].
 // ---------------------------------------------------------------------------------------------
+#ifndef HP_C2I_UB
+#define HP_C2I_UB 4
+#endif
 constexpr int kRunA = 16;   // anchors per run: the carry-in anchor is read twice (1 / 16 of the rows)
 
 template <int ND, typename T, int LPD>
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   using Raw = typename T::Raw;
   constexpr int L = ND - 1, NS = 1 << L;
   constexpr int NQ = 64 / LPD, RUNS = 4 * NQ;
-  constexpr int UB = LPD < 4 ? LPD : 4;    // row loads in flight per step
+  constexpr int UB = HP_C2I_UB;            // row loads in flight per step
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane / LPD, r = lane % LPD;
   const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;   // channels that share one list

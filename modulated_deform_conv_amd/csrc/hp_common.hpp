@@ -55,6 +55,18 @@ struct F16 {
   static __device__ __forceinline__ float dot2(float acc, u32 a, u32 b) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), acc, false);
   }
+  // acc (8 packed fp16) += w * x in PACKED fp16 arithmetic: one v_cvt_pk + four v_pk_fma_f16 per corner
+  // against eight v_fma_mix_f32 (+ the final pack).  Used only for the column value that feeds GEMM-2
+  // (col = sum of 2^ND products, rounded to fp16 for the matrix core anyway; grad_weight then averages
+  // the extra rounding over every pixel of the batch) -- never for gradients written to the caller.
+  static constexpr bool kPackedCol = true;
+  static __device__ __forceinline__ void pk_mac8(U4 &acc, const U4 &x, float w) {
+    const f16x2 w2 = {(_Float16)w, (_Float16)w};
+    auto f = [&](u32 a, u32 v) {
+      return __builtin_bit_cast(u32, __builtin_elementwise_fma(__builtin_bit_cast(f16x2, v), w2, __builtin_bit_cast(f16x2, a)));
+    };
+    acc.x = f(acc.x, x.x); acc.y = f(acc.y, x.y); acc.z = f(acc.z, x.z); acc.w = f(acc.w, x.w);
+  }
   static __device__ __forceinline__ f32x16 mfma(const U4 &a, const U4 &b, const f32x16 &c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
@@ -75,6 +87,8 @@ struct BF16 {
   static __device__ __forceinline__ float dot2(float acc, u32 a, u32 b) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
   }
+  static constexpr bool kPackedCol = false;
+  static __device__ __forceinline__ void pk_mac8(U4 &, const U4 &, float) {}
   static __device__ __forceinline__ f32x16 mfma(const U4 &a, const U4 &b, const f32x16 &c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }

@@ -25,20 +25,26 @@ namespace mdconv {
 namespace {
 
 template <typename T, int WAVES, int MB2>
-__global__ __launch_bounds__(64 * WAVES) void hp_gemm2_kernel(
+__global__ __launch_bounds__(64 * WAVES, MB2 <= 4 ? 3 : 1) void hp_gemm2_kernel(
     Geom g, HpDims hd, const int4 *__restrict__ btab, const typename T::Raw *__restrict__ gout,
     const typename T::Raw *__restrict__ colbuf, float *__restrict__ part) {
   using Raw = typename T::Raw;
   constexpr int NT = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int OpL = hd.OpL, Cp = hd.Cp, pitch = Cp + 8;
+  // column tile pitch Cp + 32 elements (16 dwords past a multiple of 64): the four rows a transposing
+  // read touches per 16-lane group land 16 banks apart -- with Cp + 8 they were 4 banks apart and the
+  // 8-byte pieces of neighbouring rows collided (1.6e8 conflict cycles per cfg5 launch)
+  const int OpL = hd.OpL, Cp = hd.Cp, pitch = Cp + 32;
   Raw *Gop = reinterpret_cast<Raw *>(smem);     // [2][OpL][kPP]   grad_out tile, [o][pixel]
   Raw *Col = Gop + 2 * OpL * kPP;               // [2][32][pitch]  column tile,   [pixel][c]
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, pl = lane & 31;
   const int cblk = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool active = cblk < hd.cblks;
-  const int tap = blockIdx.y, range = blockIdx.x;
+  // unit = (range, tap), tap fastest, contiguous runs of units per XCD (xcd_remap): the K taps of a pixel
+  // range run side by side on ONE XCD and read the same grad_out tiles -- from its L2 after the first
+  const int unit = xcd_remap(blockIdx.x, gridDim.x);
+  const int range = unit / g.K, tap = unit - range * g.K;
   const int t_lo = range * hd.tiles_per_range_w;
   const int t_hi = min(t_lo + hd.tiles_per_range_w, hd.ntiles);
   const int o_base = active ? btab[cblk].x : 0;
@@ -52,13 +58,20 @@ __global__ __launch_bounds__(64 * WAVES) void hp_gemm2_kernel(
   if (t_lo < t_hi) {
     // ---- loaders.  grad_out item = (o, pixel octet); column item = (pixel, channel octet).  (lb, lp) =
     // image / pixel of the first pixel of the tile being REQUESTED (wave-uniform) ----
-    const bool vec_ok = (g.S_o & 7) == 0;
+    // tile_ok (32 | S_o): a tile never straddles two images, so a thread's items have CONSTANT offsets from
+    // a per-tile scalar base -- buffer loads with the base in the scalar offset, no per-item address
+    // arithmetic (the generic loaders below cost ~100 VALU per item against 8 MFMAs per tile and wave)
+    const bool vec_ok = (g.S_o & 7) == 0, tile_ok = (g.S_o & 31) == 0;
+    const rsrc_t r_go = make_rsrc(gout, (size_t)g.B * g.O * g.S_o * 2);
+    const size_t col_img = (size_t)g.K * g.S_o * Cp;
     const int LPP = Cp / 8;
     const int ngitems = OpL * 4, ncitems = 32 * LPP;
     constexpr int GI = 2, CI = 2;   // items per thread kept in flight; more go through the tail loops
     int lb = (t_lo * 32) / g.S_o, lp = t_lo * 32 - lb * g.S_o;
-    auto load_g = [&](int item) -> U4 {
+    auto load_g = [&](int item, int lb, int lp) -> U4 {
       const int o = item >> 2, oct = item & 3;
+      if (tile_ok)   // images beyond the batch fall out of the buffer's range (zeros)
+        return buf_load4u(r_go, o < g.O ? (o * g.S_o + oct * 8) * 2 : kHpOob, (lb * g.O * g.S_o + lp) * 2);
       int bb = lb, pp = lp + oct * 8;
       while (pp >= g.S_o) { pp -= g.S_o; ++bb; }
       U4 v = {0, 0, 0, 0};
@@ -78,8 +91,12 @@ __global__ __launch_bounds__(64 * WAVES) void hp_gemm2_kernel(
       }
       return v;
     };
-    auto load_c = [&](int item) -> U4 {
+    auto load_c = [&](int item, int lb, int lp) -> U4 {
       const int p = item / LPP, oc = item - p * LPP;
+      if (tile_ok) {
+        const rsrc_t r_c = make_rsrc(colbuf + (size_t)min(lb, g.B - 1) * col_img, lb < g.B ? col_img * 2 : 0);
+        return buf_load4u(r_c, (p * Cp + oc * 8) * 2, ((tap * g.S_o + lp) * Cp) * 2);
+      }
       int bb = lb, pp = lp + p;
       while (pp >= g.S_o) { pp -= g.S_o; ++bb; }
       U4 v = {0, 0, 0, 0};   // pixels beyond the batch: the fused kernel never wrote those rows
@@ -93,38 +110,31 @@ __global__ __launch_bounds__(64 * WAVES) void hp_gemm2_kernel(
       const int p = item / LPP, oc = item - p * LPP;
       *reinterpret_cast<U4 *>(Col + (buf * 32 + p) * pitch + oc * 8) = v;
     };
-    U4 rg[GI], rc[CI];
-    auto request = [&]() {   // the tile at (lb, lp): first GI / CI items per thread into registers
-#pragma unroll
-      for (int i = 0; i < GI; ++i) rg[i] = tid + i * NT < ngitems ? load_g(tid + i * NT) : U4{0, 0, 0, 0};
-#pragma unroll
-      for (int i = 0; i < CI; ++i) rc[i] = tid + i * NT < ncitems ? load_c(tid + i * NT) : U4{0, 0, 0, 0};
+    // Two tiles ahead in registers (sets A and B), one more in the other LDS buffer: the kernel streams
+    // 16 KB per tile and workgroup and is paced by bytes in flight, not by its 8 MFMAs per wave and tile.
+    struct Regs { U4 g[GI], c[CI]; };
+    int qb = lb, qp = lp;   // position of the tile being PUBLISHED (its tail items are loaded on the spot)
+    auto next = [&](int &b_, int &p_) {
+      p_ += 32;
+      while (p_ >= g.S_o) { p_ -= g.S_o; ++b_; }
     };
-    auto publish = [&](int buf) {   // registers -> LDS; items beyond the in-flight ones are loaded here
+    auto request = [&](Regs &r) {   // the tile at (lb, lp): first GI / CI items per thread into registers; advances
 #pragma unroll
-      for (int i = 0; i < GI; ++i) if (tid + i * NT < ngitems) store_g(tid + i * NT, rg[i], buf);
+      for (int i = 0; i < GI; ++i) r.g[i] = tid + i * NT < ngitems ? load_g(tid + i * NT, lb, lp) : U4{0, 0, 0, 0};
 #pragma unroll
-      for (int i = 0; i < CI; ++i) if (tid + i * NT < ncitems) store_c(tid + i * NT, rc[i], buf);
-      for (int item = tid + GI * NT; item < ngitems; item += NT) store_g(item, load_g(item), buf);
-      for (int item = tid + CI * NT; item < ncitems; item += NT) store_c(item, load_c(item), buf);
+      for (int i = 0; i < CI; ++i) r.c[i] = tid + i * NT < ncitems ? load_c(tid + i * NT, lb, lp) : U4{0, 0, 0, 0};
+      next(lb, lp);
     };
-    auto advance = [&]() {
-      lp += 32;
-      while (lp >= g.S_o) { lp -= g.S_o; ++lb; }
+    auto publish = [&](const Regs &r, int buf) {   // registers -> LDS (tile at (qb, qp)); advances
+#pragma unroll
+      for (int i = 0; i < GI; ++i) if (tid + i * NT < ngitems) store_g(tid + i * NT, r.g[i], buf);
+#pragma unroll
+      for (int i = 0; i < CI; ++i) if (tid + i * NT < ncitems) store_c(tid + i * NT, r.c[i], buf);
+      for (int item = tid + GI * NT; item < ngitems; item += NT) store_g(item, load_g(item, qb, qp), buf);
+      for (int item = tid + CI * NT; item < ncitems; item += NT) store_c(item, load_c(item, qb, qp), buf);
+      next(qb, qp);
     };
-
-    request();
-    publish(0);
-    advance();
-    if (t_lo + 1 < t_hi) request();
-    __syncthreads();
-    for (int tile = t_lo; tile < t_hi; ++tile) {
-      const int buf = (tile - t_lo) & 1;
-      if (tile + 1 < t_hi) {
-        publish(buf ^ 1);   // the other buffer was last read before the barrier that ended the previous iteration
-        advance();
-        if (tile + 2 < t_hi) request();
-      }
+    auto mma = [&](int buf) {
       if (active) {
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
@@ -139,7 +149,31 @@ __global__ __launch_bounds__(64 * WAVES) void hp_gemm2_kernel(
           }
         }
       }
+    };
+
+    Regs ra, rb;
+    request(ra);
+    publish(ra, 0);
+    if (t_lo + 1 < t_hi) request(ra);
+    if (t_lo + 2 < t_hi) request(rb);
+    __syncthreads();
+    // iteration `tile`: tile + 1 goes to the other LDS buffer (last read before the barrier that ended the
+    // previous iteration), tile + 3 is requested into the register set that just emptied
+    for (int tile = t_lo; tile < t_hi; tile += 2) {
+      if (tile + 1 < t_hi) {
+        publish(ra, 1);
+        if (tile + 3 < t_hi) request(ra);
+      }
+      mma(0);
       __syncthreads();
+      if (tile + 1 < t_hi) {
+        if (tile + 2 < t_hi) {
+          publish(rb, 0);
+          if (tile + 4 < t_hi) request(rb);
+        }
+        mma(1);
+        __syncthreads();
+      }
     }
   }
   if (active) {
@@ -163,7 +197,7 @@ int launch_gemm2(const Geom &g, const HpDims &hd, const Tensors &t, const int4 *
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; }
   }
-  hipLaunchKernelGGL((hp_gemm2_kernel<T, WAVES, MB2>), dim3(hd.ranges_w, g.K), dim3(64 * WAVES), lds, stream, g, hd,
+  hipLaunchKernelGGL((hp_gemm2_kernel<T, WAVES, MB2>), dim3(hd.ranges_w * g.K), dim3(64 * WAVES), lds, stream, g, hd,
                      btab, (const Raw *)t.grad_output, (const Raw *)colbuf, part);
   return check_launch("hp_gemm2");
 }
@@ -190,7 +224,7 @@ int dispatch_gemm2(const Geom &g, const HpDims &hd, const Tensors &t, const int4
 }  // namespace
 
 size_t hp_gemm2_lds_bytes(const HpDims &hd) {
-  return (size_t)2 * hd.OpL * kPP * 2 + (size_t)2 * 32 * (hd.Cp + 8) * 2;
+  return (size_t)2 * hd.OpL * kPP * 2 + (size_t)2 * 32 * (hd.Cp + 32) * 2;
 }
 
 int hp_gemm2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const int4 *btab,
