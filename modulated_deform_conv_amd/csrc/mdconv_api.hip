@@ -152,6 +152,24 @@ int fill_geom(const mdconv_desc *d, Geom *g) {
   return MDCONV_OK;
 }
 
+// One line on stderr, once per process, when a shape with matrix-sized channel counts runs on the
+// shape-generic VALU kernels (an order of magnitude slower than the matrix-core kernels): the fp32 matrix
+// backward takes deformable groups of 64 / 128 / k * 256 channels only, and nothing else tells the user
+// (mdconv_last_kernels() reports it per call; MDCONV_QUIET=1 silences the line).
+static void note_direct_fallback(const Geom &g, int dtype, bool backward) {
+  static std::atomic<bool> said{false};
+  if (g.Cg < 16 || g.Og < 16 || dtype == MDCONV_F64 || current_path() == MDCONV_PATH_DIRECT) return;
+  if (said.exchange(true)) return;
+  const char *q = getenv("MDCONV_QUIET");
+  if (q && atoi(q) != 0) return;
+  fprintf(stderr,
+          "mdconv: %s of a %d-D shape with C_in=%d C_out=%d groups=%d deformable_groups=%d runs on the shape-generic "
+          "kernels (the matrix-core kernels need %s); expect it to be ~10x slower. This note is printed once.\n",
+          backward ? "backward" : "forward", g.nd, g.C, g.O, g.G, g.DG,
+          backward ? "C_in/deformable_groups in {64, 128, k*256} for fp32, a multiple of 32 for 16-bit tensors"
+                   : "C_in/deformable_groups a multiple of 32 (16 for 16-bit tensors)");
+}
+
 static int require(const void *p, const char *name) {
   if (!p) {
     set_error("%s pointer is NULL", name);
@@ -216,6 +234,7 @@ static int run_forward(const mdconv_desc *d, int nd, int modulated, Tensors t, v
   }
   g_last_path = MDCONV_PATH_DIRECT;
   g_last_kernels = MDCONV_KERNELS_DIRECT;
+  note_direct_fallback(g, d->dtype, false);
   return direct_forward(g, d->dtype, t, s);
 }
 
@@ -265,6 +284,7 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
   }
   g_last_path = MDCONV_PATH_DIRECT;
   g_last_kernels = MDCONV_KERNELS_DIRECT;
+  note_direct_fallback(g, d->dtype, true);
   if (d->dtype == MDCONV_F16 || d->dtype == MDCONV_BF16) {
     if ((rc = check_ws(ws, ws_bytes, direct16_workspace_bytes(g)))) return rc;
     if ((rc = direct16_backward(g, d->dtype, t, ws, s))) return rc;
