@@ -1,8 +1,10 @@
 #!/bin/bash
-# Run ON THE GPU BOX: everything profiles/r02_* is made of (beyond tools/collect_profiles.sh r02).
+# Run ON THE GPU BOX: everything profiles/<tag>_other_configs.md / <tag>_hp_counters.md are made of
+# (beyond tools/collect_profiles.sh <tag>).   usage: tools/collect_extra.sh r03
 export TMPDIR=/tmp
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-D=$ROOT/gpurun_out/r02_extra
+TAG=${1:-r03}
+D=$ROOT/gpurun_out/${TAG}_extra
 rm -rf $D; mkdir -p $D
 cd $ROOT
 {
@@ -10,6 +12,10 @@ cd $ROOT
   python tools/bench_configs.py cfg3 cfg4 cfg5 2>&1 | grep -v amdgpu.ids
   echo "## cfg2 strong-scaling shards on 1 GPU: B = 32 / 16 / 8 / 4 (predicted ceiling of --scaling strong)"
   python tools/bench_configs.py cfg2 cfg2:16 cfg2:8 cfg2:4 2>&1 | grep -v amdgpu.ids
+  echo "## the same shards replayed from a HIP graph (no host launch latency in the loop)"
+  python tools/bench_configs.py cfg2 cfg2:16 cfg2:8 cfg2:4 --graph 2>&1 | grep -v amdgpu.ids
+  echo "## 16-bit configurations with the round-2 kernels: MDCONV_HP_BWD=2 (fused tap-stationary backward), MDCONV_HP_C2I=1 (one-pass gather)"
+  MDCONV_HP_BWD=2 MDCONV_HP_C2I=1 python tools/bench_configs.py cfg3 cfg5 2>&1 | grep -v amdgpu.ids
   echo "## same with the 16-bit path disabled (round-1 widen/narrow through the fp32 kernels)"
   MDCONV_HP=0 python tools/bench_configs.py cfg3 cfg5 2>&1 | grep -v amdgpu.ids
 } > $D/configs.txt 2>&1

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/<tag>_extra/ (tools/collect_r02.sh, run on the GPU box) into the two committed
+"""Turn gpurun_out/<tag>_extra/ (tools/collect_extra.sh, run on the GPU box) into the two committed
 summaries profiles/<tag>_other_configs.md and profiles/<tag>_hp_counters.md.
-usage: python tools/summarize_extra.py r02"""
+usage: python tools/summarize_extra.py r03"""
 import collections
 import csv
 import os
@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag + "_extra")
 prof = os.path.join(ROOT, "profiles")
 
@@ -36,10 +36,12 @@ def stats(cfg):
 
 # ---------------------------------------------------------------- other configs
 o = ["# %s -- the other BASELINE.json configurations on one MI355X (not bench lines)" % tag, "",
-     "Collected by `tools/collect_r02.sh` on the GPU box (same build as `profiles/%s_summary.md`); per-GPU" % tag,
-     "shards of the configurations, default kernel path, mean of 5 calls after a warm-up",
-     "(`tools/bench_configs.py`; the Python entry points allocate their outputs inside the timed call,",
-     "so cfg2 reads ~0.5 ms above `bench.py`, which drives the C ABI on preallocated buffers).", "",
+     "Collected by `tools/collect_extra.sh` on the GPU box (same build as `profiles/%s_summary.md`); per-GPU" % tag,
+     "shards of the configurations, default kernel path, mean of 10 calls after a warm-up",
+     "(`tools/bench_configs.py`, the workload definitions of `bench.py`).  The eager lines go through the same",
+     "allocating Python entry points as `bench.py`; short eager loops of small shards expose the host's launch",
+     "latency (about 14 launches and 7 allocations per step), so the strong-scaling shards are quoted from the",
+     "`--graph` lines (a captured step replayed 20 times).", "",
      "```", read("configs.txt").strip(), "```", "",
      "The kernel-path tag printed by the script is the library's `mdconv_last_path`: `mfma` covers both the",
      "fp32 MFMA kernels and the native 16-bit (`hp_*`) kernels; the kernel names below tell them apart.", "",

@@ -71,7 +71,7 @@ def main(src, tag):
             pmc[k]["launches_" + counter] = len(v)
     summary = {}
     for k, v in pmc.items():
-        if not k.startswith(("mfma_", "col2im", "pack_", "csr_", "tap_", "grad_bias", "reduce_")):
+        if not k.startswith(("mfma_", "col2im", "pack_", "csr_", "tap_", "grad_bias", "reduce_", "nchw_", "zero_")):
             continue
         f_raw = v.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024
         wr = v.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
@@ -91,9 +91,9 @@ def main(src, tag):
     with open(os.path.join(out_dir, tag + "_summary.md"), "w") as f:
         f.write("# %s -- rocprofv3 summary of `python bench.py` (MI355X, cfg2: MDCN2d 3x3 C=256 56x56 B=32 fp32)\n\n" % tag)
         f.write("Commands (on the GPU box, `cd /tmp && export TMPDIR=/tmp`):\n\n"
-                "    rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline\n"
-                "    rocprofv3 --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n"
-                "    rocprofv3 --pmc WRITE_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n\n")
+                "    rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs\n"
+                "    rocprofv3 --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs\n"
+                "    rocprofv3 --pmc WRITE_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs\n\n")
         f.write("## Kernel time (--kernel-trace --stats)\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n")
         for r in stats[:16]:
             f.write("| %s | %s | %.1f | %s |\n" % (short(r["Name"])[:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
@@ -104,6 +104,11 @@ def main(src, tag):
                                                           v["write_bytes"] / 1e6, v["hbm_bytes_per_launch"] / 1e6))
         if bench_json:
             f.write("\n## bench.py line of the same build (un-profiled run)\n\n```\n%s\n```\n" % bench_json)
+        for extra, title in (("bench_graph.json", "same build, `--graph` (step replayed from a HIP graph)"),
+                             ("bench_nofork.json", "same build, `MDCONV_BWD_FORK=0` (grad_input gather AFTER GEMM-2 on the caller's stream, the round-2 order)")):
+            pe = os.path.join(src, extra)
+            if os.path.exists(pe) and open(pe).read().strip():
+                f.write("\n## %s\n\n```\n%s\n```\n" % (title, open(pe).read().strip()))
     print("wrote profiles/%s_*" % tag)
 
 
