@@ -1208,8 +1208,8 @@ int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, 
 }
 
 int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol,
-               const int *rowptr, const void *entries, hipStream_t stream) {
-  if (bd.sample_keyed) return col2im3d_f32(g, bd, t, gcol, rowptr, entries, stream);
+               const int *rowptr, const void *entries, float *sums, hipStream_t stream) {
+  if (bd.sample_keyed) return col2im3d_f32(g, bd, t, gcol, rowptr, entries, sums, stream);
   const int qtiles = (g.S_i + 31) / 32;
   const dim3 grid(g.B * qtiles, 1);
 #define LAUNCH_GG(ND, LPD)                                                                      \

@@ -209,6 +209,143 @@ __global__ __launch_bounds__(256) void col2im3d_kernel(Geom g, int S_e, const fl
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-pass gather (round 3; the scheme of hp_col2im.hip in fp32): every grad_col row and every list
+// entry is read ONCE.  The block walk above still fetches a row 9/4 times -- 2.5 GB (raw FETCH_SIZE) for
+// the 1.8 GB of rows at cfg4, L2 hit 7 %.  Pass 1 walks ANCHOR rows and keeps, per anchor column, one
+// partial sum for each of the 4 target rows (z - 1 | z, y - 1 | y) an anchor row feeds -- the same
+// multiply-adds, spread over 4 accumulator sets -- written as fp32 rows A[segment][anchor][s][channels];
+// pass 2 is a 4-point stencil over A (target t takes s from anchor row t + s) + the transpose to NCDHW.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRunA3 = 16;   // anchors per run: the carry-in anchor is read twice (1 / 16 of the rows)
+
+template <int LPD>
+__global__ __launch_bounds__(256) void col2im3d_sums_kernel(Geom g, int S_e, const float *__restrict__ gcol,
+                                                            const int *__restrict__ rowptr,
+                                                            const int4 *__restrict__ entries,
+                                                            float *__restrict__ sums) {
+  constexpr int NS = 4, NQ = 64 / LPD, RUNS = 4 * NQ;
+  constexpr int UB = 4;    // row loads in flight per step
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane / LPD, r = lane % LPD;
+  const int cseg = g.DG == 1 ? g.C : g.Cdg;     // channels that share one list
+  const int runs_per_seg = (S_e + kRunA3 - 1) / kRunA3;
+  const int blocks_per_seg = (runs_per_seg + RUNS - 1) / RUNS;
+  const int seg = blockIdx.x / blocks_per_seg;                  // b * DG + dg
+  const int run = (blockIdx.x - seg * blocks_per_seg) * RUNS + wave * NQ + j;
+  const int b = seg / g.DG, dg = seg - b * g.DG;
+  const int a_lo = run * kRunA3;
+  if (a_lo >= S_e) return;
+  const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * g.C, (size_t)g.K * g.S_o * g.C * 4);
+  const int *rp = rowptr + (int64_t)seg * (S_e + 1);
+  const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * 2;
+  // channel units of LPD * 4 channels (more than 256 channels per list: the lists are walked once per unit)
+  for (int cu = 0; cu < cseg; cu += LPD * 4) {
+  const bool chan_on = cu + r * 4 < cseg;
+  const int c_voff = chan_on ? (dg * cseg + cu + r * 4) * 4 : kOob3;
+  float *out = sums + ((int64_t)seg * S_e * NS) * cseg + cu + r * 4;
+  float4 cur[NS], nxt[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) cur[s] = nxt[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int step = 0; step <= kRunA3; ++step) {
+    const int ea = a_lo - 1 + step;
+    const bool on = ea >= 0 && ea < S_e;
+    const int e0 = on ? rp[ea] : 0, e1 = on ? rp[ea + 1] : 0;
+    for (int base = e0; __any(base < e1); base += LPD) {
+      const int cnt = max(0, min(LPD, e1 - base));
+      int src_m = 0;
+      float wx_m = 0.f, wy_m = 0.f, fa_m[NS] = {0.f, 0.f, 0.f, 0.f};   // weights 0, row 0 beyond the list
+      if (r < cnt) {
+        const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
+        src_m = ea4.x;
+        wx_m = __int_as_float(ea4.y); wy_m = __int_as_float(ea4.z);
+        const float zl = __int_as_float(ea4.w), zh = __int_as_float(eb4.x);
+        const float yl = __int_as_float(eb4.y), yh = __int_as_float(eb4.z);
+        // s: bit 1 = the target one lower in z (low weight), bit 0 = one lower in y
+        fa_m[0] = zh * yh; fa_m[1] = zh * yl; fa_m[2] = zl * yh; fa_m[3] = zl * yl;
+      }
+#pragma unroll 1
+      for (int u0 = 0; u0 < LPD; u0 += UB) {
+        if (!__any(u0 < cnt)) break;   // (wave-uniform) no run of this wave has entries left in the batch
+        float4 v[UB];
+        float wx[UB], wy[UB], fa[UB][NS];
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+          const int src = __shfl(src_m, u0 + k, LPD);
+          wx[k] = __shfl(wx_m, u0 + k, LPD);
+          wy[k] = __shfl(wy_m, u0 + k, LPD);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) fa[k][s] = __shfl(fa_m[s], u0 + k, LPD);
+          v[k] = buf_load4(r_gc, src * g.C * 4 + c_voff, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            const float ax = fa[k][s] * wx[k], ay = fa[k][s] * wy[k];
+            cur[s].x = fmaf(ax, v[k].x, cur[s].x); cur[s].y = fmaf(ax, v[k].y, cur[s].y);
+            cur[s].z = fmaf(ax, v[k].z, cur[s].z); cur[s].w = fmaf(ax, v[k].w, cur[s].w);
+            nxt[s].x = fmaf(ay, v[k].x, nxt[s].x); nxt[s].y = fmaf(ay, v[k].y, nxt[s].y);
+            nxt[s].z = fmaf(ay, v[k].z, nxt[s].z); nxt[s].w = fmaf(ay, v[k].w, nxt[s].w);
+          }
+      }
+    }
+    if (step > 0 && on && chan_on) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<float4 *>(out + ((int64_t)ea * NS + s) * cseg) = cur[s];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { cur[s] = nxt[s]; nxt[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  }
+  }
+}
+
+// pass 2: grad_input[b][c][t] (+)= sum_s A[segment(b, c)][anchor row t + s][x][s][c]; workgroup = 64
+// consecutive targets x 64 channels, lanes = (target, channel quad), LDS transpose to [B, C, S_i]
+__global__ __launch_bounds__(256) void col2im3d_combine_kernel(Geom g, int S_e, const float *__restrict__ sums,
+                                                               float *__restrict__ grad_input) {
+  constexpr int NS = 4, QT = 64, CW = 64, TP = QT + 1;
+  __shared__ float tile[CW * TP];
+  const int qtiles = (g.S_i + QT - 1) / QT;
+  const int b = blockIdx.x / qtiles, q0 = (blockIdx.x - b * qtiles) * QT;
+  const int cseg = g.DG == 1 ? g.C : g.Cdg;
+  const int D = g.in_sz[0], H = g.in_sz[1], W = g.in_sz[2];
+  (void)D;
+  for (int c0 = 0; c0 < g.C; c0 += CW) {
+    // 16 lanes per target (64 channels), 16 targets per pass
+    for (int it = 0; it < QT / 16; ++it) {
+      const int ql = it * 16 + (threadIdx.x >> 4), q = q0 + ql;
+      const int c = c0 + (threadIdx.x & 15) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < g.S_i && c < g.C) {
+        const int dg = g.DG == 1 ? 0 : c / cseg;
+        const int cl = c - dg * cseg;
+        const int x = q % W, y = (q / W) % H, z = q / (W * H);
+        const float *base = sums + ((int64_t)(b * g.DG + dg) * S_e * NS) * cseg + cl;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int er = (z + (s >> 1)) * (H + 1) + y + (s & 1);
+          const float4 v = *reinterpret_cast<const float4 *>(base + (((int64_t)er * W + x) * NS + s) * cseg);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+      float *tp = tile + ((threadIdx.x & 15) * 4) * TP + ql;
+      tp[0] = acc.x; tp[TP] = acc.y; tp[2 * TP] = acc.z; tp[3 * TP] = acc.w;
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < CW * QT; x += 256) {
+      const int cl = x / QT, ql = x - cl * QT;
+      const int c = c0 + cl, q = q0 + ql;
+      if (c < g.C && q < g.S_i) {
+        float *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q;
+        const float v = tile[cl * TP + ql];
+        *dst = g.acc_data ? *dst + v : v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 int csr_fill3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cursor,
@@ -223,10 +360,35 @@ int csr_fill3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *curs
   return check_launch("csr_fill3d");
 }
 
+size_t col2im3d_sums_bytes(const Geom &g) {
+  const size_t cseg = g.DG == 1 ? g.C : g.Cdg;
+  return (size_t)g.B * g.DG * hp_anchor_space(g) * 4 * cseg * sizeof(float);
+}
+
 int col2im3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol,
-                 const int *rowptr, const void *entries, hipStream_t stream) {
+                 const int *rowptr, const void *entries, float *sums, hipStream_t stream) {
   const int cseg = g.DG == 1 ? g.C : g.Cdg;
   const int lanes = (cseg + 3) / 4;
+  if (bd.two_pass) {
+    const int runs_per_seg = (bd.S_e + kRunA3 - 1) / kRunA3;
+#define C2S3(LPD)                                                                                \
+  do {                                                                                           \
+    const int runs = 4 * (64 / LPD);                                                             \
+    hipLaunchKernelGGL((col2im3d_sums_kernel<LPD>), dim3(g.B * g.DG * ((runs_per_seg + runs - 1) / runs)), \
+                       dim3(256), 0, stream, g, bd.S_e, gcol, rowptr, (const int4 *)entries, sums); \
+  } while (0)
+    if (lanes <= 4) C2S3(4);
+    else if (lanes <= 8) C2S3(8);
+    else if (lanes <= 16) C2S3(16);
+    else if (lanes <= 32) C2S3(32);
+    else C2S3(64);
+#undef C2S3
+    int rc = check_launch("col2im3d_sums");
+    if (rc) return rc;
+    hipLaunchKernelGGL(col2im3d_combine_kernel, dim3(g.B * ((g.S_i + 63) / 64)), dim3(256), 0, stream, g, bd.S_e,
+                       sums, (float *)t.grad_input);
+    return check_launch("col2im3d_combine");
+  }
 #define C2I3(LPD)                                                                                \
   do {                                                                                           \
     const int runs = 4 * (64 / LPD);                                                             \

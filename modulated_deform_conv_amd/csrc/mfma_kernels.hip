@@ -170,6 +170,9 @@ BwdDims bwd_dims(const Geom &g) {
   bd.bias_tiles = (g.N + 32 * (4 / bd.waves_c) - 1) / (32 * (4 / bd.waves_c));
   bd.off_bias = off; off += align_up((size_t)bd.bias_tiles * g.O * sizeof(float));
   bd.off_xt = off;   off += bd.cl ? align_up((size_t)g.B * g.S_i * g.C * sizeof(float)) : 0;
+  static const int c2i_env = getenv("MDCONV_C2I3D") ? atoi(getenv("MDCONV_C2I3D")) : 2;
+  bd.two_pass = bd.sample_keyed && c2i_env >= 2 ? 1 : 0;
+  bd.off_sums = off; off += bd.two_pass ? align_up(col2im3d_sums_bytes(g)) : 0;
   bd.off_end = off;
   return bd;
 }
@@ -390,8 +393,8 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
     if (weights_final && (rc = record_weight_ready(stream))) return rc;
   }
   if ((rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, gs))) return rc;
-  profile_mark(3, true, gs, bd.sample_keyed ? "col2im3d_kernel" : "col2im_gather_kernel");
-  rc = col2im_f32(g, bd, t, gcol, rowptr, entries, gs);
+  profile_mark(3, true, gs, bd.sample_keyed ? (bd.two_pass ? "col2im3d_sums_kernel" : "col2im3d_kernel") : "col2im_gather_kernel");
+  rc = col2im_f32(g, bd, t, gcol, rowptr, entries, (float *)(base + bd.off_sums), gs);
   profile_mark(3, false, gs);
   if (rc) return rc;
   if (fork) {

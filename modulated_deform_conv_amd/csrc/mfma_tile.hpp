@@ -87,7 +87,8 @@ struct BwdDims {
   int sample_keyed;     // scatter lists: 1 = one entry per SAMPLE (3-D, mfma_csr3d.hip), 0 = per corner pair
   int S_e;              // list heads per (image, deformable group): anchor space (3-D) or S_i
   size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
-      off_xt, off_end;
+      off_xt, off_sums, off_end;   // off_sums: per-anchor partial sums of the two-pass 3-D gather (0 bytes otherwise)
+  int two_pass;         // 3-D grad_input gather: 1 = per-anchor partial sums + stencil (mfma_csr3d.hip), 0 = block walk
 };
 BwdDims bwd_dims(const Geom &g);
 
@@ -124,11 +125,12 @@ int csr_zero_f32(const Geom &g, const BwdDims &bd, int *cnt, hipStream_t stream)
 int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, int *rowptr,
                   void *entries, hipStream_t stream);
 int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol,
-               const int *rowptr, const void *entries, hipStream_t stream);
+               const int *rowptr, const void *entries, float *sums, hipStream_t stream);
 // 3-D: scatter lists keyed by sample (mfma_csr3d.hip)
 int csr_fill3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cursor,
                    const int *rowptr, void *entries, hipStream_t stream);
 int col2im3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol,
-                 const int *rowptr, const void *entries, hipStream_t stream);
+                 const int *rowptr, const void *entries, float *sums, hipStream_t stream);
+size_t col2im3d_sums_bytes(const Geom &g);
 
 }  // namespace mdconv
