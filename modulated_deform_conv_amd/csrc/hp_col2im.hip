@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void hp_csr_scan_kernel(int S, const int *__re
   if (hi == S && threadIdx.x == 0) rp[S] = carry;
 }
 
-// entry = 2 x int4: (src, wx, wy, rl0), (rh0, rl1, rh1, 0)
+// entry = 2 x int4: (src, wx, wy, rl0), (rh0, rl1, rh1, anchor)
 template <int ND, bool MOD, typename T>
 __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
                                                           const typename T::Raw *__restrict__ offset,
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
       int4 *e = entries + ((int64_t)seg * ((int64_t)g.K * g.S_o) + pos) * 2;
       e[0] = make_int4(tap * g.S_o + pix, __float_as_int(sa.wx), __float_as_int(sa.wy), __float_as_int(sa.rl[0]));
       e[1] = make_int4(__float_as_int(sa.rh[0]), __float_as_int(ND == 3 ? sa.rl[ND - 2] : 0.f),
-                       __float_as_int(ND == 3 ? sa.rh[ND - 2] : 0.f), 0);
+                       __float_as_int(ND == 3 ? sa.rh[ND - 2] : 0.f), sa.qa);
     }
   }
 }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   using Raw = typename T::Raw;
   constexpr int L = ND - 1, NS = 1 << L;
   constexpr int NQ = 64 / LPD, RUNS = 4 * NQ;
-  constexpr int UB = HP_C2I_UB;            // row loads in flight per step
+  constexpr int UB = HP_C2I_UB;            // rows per load group; two groups are in flight
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane / LPD, r = lane % LPD;
   const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;   // channels that share one list
@@ -265,73 +265,100 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   const int seg = blockIdx.x / blocks_per_seg;                  // b * DG + dg
   const int run = (blockIdx.x - seg * blocks_per_seg) * RUNS + wave * NQ + j;
   const int b = seg / g.DG, dg = seg - b * g.DG;
-  const int a_lo = run * kRunA;                                 // first anchor of this run
-  if (a_lo >= S_e) return;
+  const bool run_on = run * kRunA < S_e;
+  const int a_lo = run_on ? run * kRunA : 0;                    // first anchor this run writes
+  const int a_last = run_on ? min(a_lo + kRunA, S_e) - 1 : -1;  // last one
   const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * hd.Cp, (size_t)g.K * g.S_o * hd.Cp * 2);
   const int *rp = rowptr + (int64_t)seg * (S_e + 1);
   const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * 2;
   const bool chan_on = r * 8 < cseg;
   const int c_voff = chan_on ? (dg * cseg + r * 8) * 2 : kHpOob;
   Raw *out = sums + ((int64_t)seg * S_e * NS) * cseg + r * 8;
+  // The lists of consecutive anchors are contiguous in `entries`, so a run streams ONE entry range --
+  // from the carry-in anchor a_lo - 1 (only its column + 1 part lands in this run) to a_last -- in
+  // batches of LPD entries, rows loaded UB at a time with two groups in flight; an entry names its
+  // anchor, and the accumulators are flushed whenever the anchor advances (empty anchors included).
+  // No per-anchor rowptr -> entry -> row dependency chain is left.
+  const int e_end = run_on ? rp[a_last + 1] : 0;
+  int e_pos = run_on ? rp[max(a_lo - 1, 0)] : 0;
+  int cur_a = a_lo - 1;
   float cur[NS][8], nxt[NS][8];
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int k = 0; k < 8; ++k) cur[s][k] = nxt[s][k] = 0.f;
-  for (int step = 0; step <= kRunA; ++step) {
-    const int ea = a_lo - 1 + step;
-    const bool on = ea >= 0 && ea < S_e;
-    const int e0 = on ? rp[ea] : 0, e1 = on ? rp[ea + 1] : 0;
-    for (int base = e0; __any(base < e1); base += LPD) {
-      const int cnt = max(0, min(LPD, e1 - base));
-      int src_m = 0;
-      float wx_m = 0.f, wy_m = 0.f, f0l = 0.f, f0h = 0.f, f1l = 0.f, f1h = 0.f;   // weights 0, row 0 beyond the list
-      if (r < cnt) {
-        const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
-        src_m = ea4.x;
-        wx_m = __int_as_float(ea4.y); wy_m = __int_as_float(ea4.z);
-        f0l = __int_as_float(ea4.w); f0h = __int_as_float(eb4.x);
-        f1l = __int_as_float(eb4.y); f1h = __int_as_float(eb4.z);
-      }
-      // per-row factors of the NS sums: first outer axis (rl, rh) x (3-D) second outer axis
-      float fa_m[NS];
-      if constexpr (ND == 2) { fa_m[0] = f0h; fa_m[1] = f0l; }
-      else { fa_m[0] = f0h * f1h; fa_m[1] = f0h * f1l; fa_m[2] = f0l * f1h; fa_m[3] = f0l * f1l; }
-#pragma unroll 1
-      for (int u0 = 0; u0 < LPD; u0 += UB) {
-        if (!__any(u0 < cnt)) break;   // (wave-uniform) no run of this wave has entries left in the batch
-        {
-          U4 v[UB];
-          float wx[UB], wy[UB], fa[UB][NS];
-#pragma unroll
-          for (int k = 0; k < UB; ++k) {
-            const int src = __shfl(src_m, u0 + k, LPD);
-            wx[k] = __shfl(wx_m, u0 + k, LPD);
-            wy[k] = __shfl(wy_m, u0 + k, LPD);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) fa[k][s] = __shfl(fa_m[s], u0 + k, LPD);
-            v[k] = buf_load4u(r_gc, src * hd.Cp * 2 + c_voff, 0);
-          }
-#pragma unroll
-          for (int k = 0; k < UB; ++k)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-              mac8<T>(cur[s], v[k], fa[k][s] * wx[k]);
-              mac8<T>(nxt[s], v[k], fa[k][s] * wy[k]);
-            }
-        }
-      }
-    }
-    if (step > 0 && on && chan_on) {
+  auto flush = [&]() {   // anchor cur_a is complete: write its sums (not for the carry-in anchor), shift the column carry
+    if (cur_a >= a_lo && chan_on) {
 #pragma unroll
       for (int s = 0; s < NS; ++s)
-        *reinterpret_cast<U4 *>(out + ((int64_t)ea * NS + s) * cseg) = pack8<T>(cur[s]);
+        *reinterpret_cast<U4 *>(out + ((int64_t)cur_a * NS + s) * cseg) = pack8<T>(cur[s]);
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int k = 0; k < 8; ++k) { cur[s][k] = nxt[s][k]; nxt[s][k] = 0.f; }
+    ++cur_a;
+  };
+  while (__any(e_pos < e_end)) {
+    // this lane's entry of the batch
+    int src_m = 0, anc_m = 0x7fffffff;
+    float wx_m = 0.f, wy_m = 0.f, fa_m[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fa_m[s] = 0.f;
+    if (e_pos + r < e_end) {
+      const int4 ea4 = ent[(int64_t)(e_pos + r) * 2], eb4 = ent[(int64_t)(e_pos + r) * 2 + 1];
+      src_m = ea4.x;
+      wx_m = __int_as_float(ea4.y); wy_m = __int_as_float(ea4.z);
+      const float f0l = __int_as_float(ea4.w), f0h = __int_as_float(eb4.x);
+      if constexpr (ND == 2) { fa_m[0] = f0h; fa_m[1] = f0l; }
+      else {
+        const float f1l = __int_as_float(eb4.y), f1h = __int_as_float(eb4.z);
+        fa_m[0] = f0h * f1h; fa_m[1] = f0h * f1l; fa_m[2] = f0l * f1h; fa_m[3] = f0l * f1l;
+      }
+      anc_m = eb4.w;
+    }
+    const int cnt = max(0, min(LPD, e_end - e_pos));
+    U4 va[UB], vb[UB];
+    auto load_group = [&](U4 (&v)[UB], int u0) {
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        const int src = __shfl(src_m, u0 + k, LPD);
+        v[k] = buf_load4u(r_gc, src * hd.Cp * 2 + c_voff, 0);
+      }
+    };
+    auto use_group = [&](const U4 (&v)[UB], int u0) {
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        const int anc = __shfl(anc_m, u0 + k, LPD);
+        const float wx = __shfl(wx_m, u0 + k, LPD), wy = __shfl(wy_m, u0 + k, LPD);
+        float fa[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fa[s] = __shfl(fa_m[s], u0 + k, LPD);
+        if (u0 + k < cnt) {
+          while (cur_a < anc) flush();
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            mac8<T>(cur[s], v[k], fa[s] * wx);
+            mac8<T>(nxt[s], v[k], fa[s] * wy);
+          }
+        }
+      }
+    };
+    static_assert(LPD % (2 * UB) == 0 || LPD == UB, "batch = an even number of load groups");
+    load_group(va, 0);
+#pragma unroll 1
+    for (int u0 = 0; u0 < LPD; u0 += 2 * UB) {
+      if (!__any(u0 < cnt)) break;          // (wave-uniform) nothing left in the batch for any run of the wave
+      if (LPD > UB) load_group(vb, u0 + UB);
+      use_group(va, u0);
+      if (LPD > UB) {
+        if (u0 + 2 * UB < LPD) load_group(va, u0 + 2 * UB);
+        use_group(vb, u0 + UB);
+      }
+    }
+    e_pos += LPD;
   }
+  while (cur_a <= a_last) flush();
 }
 
 // pass 2: grad_input[b][c][t] (+)= sum_s A[segment(b, c)][anchor row t + s][x][s][c]; workgroup = 64

@@ -27,7 +27,7 @@ int grid_for3(int64_t total) {
 }
 
 // entry = 2 x int4: (tap * S_o + pixel, w(col), w(col + 1), low weight axis 0),
-//                   (high weight axis 0, low weight axis 1, high weight axis 1, 0); mask in the column weights
+//                   (high weight axis 0, low weight axis 1, high weight axis 1, anchor); mask in the column weights
 template <bool MOD>
 __global__ __launch_bounds__(256) void csr_fill3d_kernel(Geom g, int S_e, const float *__restrict__ offset,
                                                          const float *__restrict__ mask,
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void csr_fill3d_kernel(Geom g, int S_e, const 
       const int pos = rowptr[(int64_t)seg * (S_e + 1) + sa.qa] + atomicAdd(cursor + (int64_t)seg * S_e + sa.qa, 1);
       int4 *e = entries + ((int64_t)seg * ((int64_t)g.K * g.S_o) + pos) * 2;
       e[0] = make_int4(tap * g.S_o + pix, __float_as_int(sa.wx), __float_as_int(sa.wy), __float_as_int(sa.rl[0]));
-      e[1] = make_int4(__float_as_int(sa.rh[0]), __float_as_int(sa.rl[1]), __float_as_int(sa.rh[1]), 0);
+      e[1] = make_int4(__float_as_int(sa.rh[0]), __float_as_int(sa.rl[1]), __float_as_int(sa.rh[1]), sa.qa);
     }
   }
 }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void col2im3d_sums_kernel(Geom g, int S_e, con
                                                             const int4 *__restrict__ entries,
                                                             float *__restrict__ sums) {
   constexpr int NS = 4, NQ = 64 / LPD, RUNS = 4 * NQ;
-  constexpr int UB = 4;    // row loads in flight per step
+  constexpr int UB = 4;    // rows per load group; two groups are in flight
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane / LPD, r = lane % LPD;
   const int cseg = g.DG == 1 ? g.C : g.Cdg;     // channels that share one list
@@ -234,69 +234,93 @@ __global__ __launch_bounds__(256) void col2im3d_sums_kernel(Geom g, int S_e, con
   const int seg = blockIdx.x / blocks_per_seg;                  // b * DG + dg
   const int run = (blockIdx.x - seg * blocks_per_seg) * RUNS + wave * NQ + j;
   const int b = seg / g.DG, dg = seg - b * g.DG;
-  const int a_lo = run * kRunA3;
-  if (a_lo >= S_e) return;
+  const bool run_on = run * kRunA3 < S_e;
+  const int a_lo = run_on ? run * kRunA3 : 0;                    // first anchor this run writes
+  const int a_last = run_on ? min(a_lo + kRunA3, S_e) - 1 : -1;  // last one
   const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * g.C, (size_t)g.K * g.S_o * g.C * 4);
   const int *rp = rowptr + (int64_t)seg * (S_e + 1);
   const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * 2;
   // channel units of LPD * 4 channels (more than 256 channels per list: the lists are walked once per unit)
   for (int cu = 0; cu < cseg; cu += LPD * 4) {
-  const bool chan_on = cu + r * 4 < cseg;
-  const int c_voff = chan_on ? (dg * cseg + cu + r * 4) * 4 : kOob3;
-  float *out = sums + ((int64_t)seg * S_e * NS) * cseg + cu + r * 4;
-  float4 cur[NS], nxt[NS];
+    const bool chan_on = cu + r * 4 < cseg;
+    const int c_voff = chan_on ? (dg * cseg + cu + r * 4) * 4 : kOob3;
+    float *out = sums + ((int64_t)seg * S_e * NS) * cseg + cu + r * 4;
+    // The lists of consecutive anchors are contiguous in `entries`: a run streams ONE entry range, from
+    // the carry-in anchor a_lo - 1 (only its column + 1 part lands here) to a_last, in batches of LPD
+    // entries, rows loaded UB at a time with two groups in flight; an entry names its anchor and the
+    // accumulators are flushed whenever the anchor advances (empty anchors included).
+    const int e_end = run_on ? rp[a_last + 1] : 0;
+    int e_pos = run_on ? rp[max(a_lo - 1, 0)] : 0;
+    int cur_a = a_lo - 1;
+    float4 cur[NS], nxt[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) cur[s] = nxt[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int step = 0; step <= kRunA3; ++step) {
-    const int ea = a_lo - 1 + step;
-    const bool on = ea >= 0 && ea < S_e;
-    const int e0 = on ? rp[ea] : 0, e1 = on ? rp[ea + 1] : 0;
-    for (int base = e0; __any(base < e1); base += LPD) {
-      const int cnt = max(0, min(LPD, e1 - base));
-      int src_m = 0;
-      float wx_m = 0.f, wy_m = 0.f, fa_m[NS] = {0.f, 0.f, 0.f, 0.f};   // weights 0, row 0 beyond the list
-      if (r < cnt) {
-        const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
+    for (int s = 0; s < NS; ++s) cur[s] = nxt[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto flush = [&]() {   // anchor cur_a is complete: write its sums (not for the carry-in anchor), shift the column carry
+      if (cur_a >= a_lo && chan_on) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<float4 *>(out + ((int64_t)cur_a * NS + s) * cseg) = cur[s];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { cur[s] = nxt[s]; nxt[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      ++cur_a;
+    };
+    while (__any(e_pos < e_end)) {
+      int src_m = 0, anc_m = 0x7fffffff;
+      float wx_m = 0.f, wy_m = 0.f, fa_m[NS] = {0.f, 0.f, 0.f, 0.f};
+      if (e_pos + r < e_end) {
+        const int4 ea4 = ent[(int64_t)(e_pos + r) * 2], eb4 = ent[(int64_t)(e_pos + r) * 2 + 1];
         src_m = ea4.x;
         wx_m = __int_as_float(ea4.y); wy_m = __int_as_float(ea4.z);
         const float zl = __int_as_float(ea4.w), zh = __int_as_float(eb4.x);
         const float yl = __int_as_float(eb4.y), yh = __int_as_float(eb4.z);
         // s: bit 1 = the target one lower in z (low weight), bit 0 = one lower in y
         fa_m[0] = zh * yh; fa_m[1] = zh * yl; fa_m[2] = zl * yh; fa_m[3] = zl * yl;
+        anc_m = eb4.w;
       }
-#pragma unroll 1
-      for (int u0 = 0; u0 < LPD; u0 += UB) {
-        if (!__any(u0 < cnt)) break;   // (wave-uniform) no run of this wave has entries left in the batch
-        float4 v[UB];
-        float wx[UB], wy[UB], fa[UB][NS];
+      const int cnt = max(0, min(LPD, e_end - e_pos));
+      float4 va[UB], vb[UB];
+      auto load_group = [&](float4 (&v)[UB], int u0) {
 #pragma unroll
         for (int k = 0; k < UB; ++k) {
           const int src = __shfl(src_m, u0 + k, LPD);
-          wx[k] = __shfl(wx_m, u0 + k, LPD);
-          wy[k] = __shfl(wy_m, u0 + k, LPD);
-#pragma unroll
-          for (int s = 0; s < NS; ++s) fa[k][s] = __shfl(fa_m[s], u0 + k, LPD);
           v[k] = buf_load4(r_gc, src * g.C * 4 + c_voff, 0);
         }
+      };
+      auto use_group = [&](const float4 (&v)[UB], int u0) {
 #pragma unroll
-        for (int k = 0; k < UB; ++k)
+        for (int k = 0; k < UB; ++k) {
+          const int anc = __shfl(anc_m, u0 + k, LPD);
+          const float wx = __shfl(wx_m, u0 + k, LPD), wy = __shfl(wy_m, u0 + k, LPD);
+          float fa[NS];
 #pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            const float ax = fa[k][s] * wx[k], ay = fa[k][s] * wy[k];
-            cur[s].x = fmaf(ax, v[k].x, cur[s].x); cur[s].y = fmaf(ax, v[k].y, cur[s].y);
-            cur[s].z = fmaf(ax, v[k].z, cur[s].z); cur[s].w = fmaf(ax, v[k].w, cur[s].w);
-            nxt[s].x = fmaf(ay, v[k].x, nxt[s].x); nxt[s].y = fmaf(ay, v[k].y, nxt[s].y);
-            nxt[s].z = fmaf(ay, v[k].z, nxt[s].z); nxt[s].w = fmaf(ay, v[k].w, nxt[s].w);
+          for (int s = 0; s < NS; ++s) fa[s] = __shfl(fa_m[s], u0 + k, LPD);
+          if (u0 + k < cnt) {
+            while (cur_a < anc) flush();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              const float ax = fa[s] * wx, ay = fa[s] * wy;
+              cur[s].x = fmaf(ax, v[k].x, cur[s].x); cur[s].y = fmaf(ax, v[k].y, cur[s].y);
+              cur[s].z = fmaf(ax, v[k].z, cur[s].z); cur[s].w = fmaf(ax, v[k].w, cur[s].w);
+              nxt[s].x = fmaf(ay, v[k].x, nxt[s].x); nxt[s].y = fmaf(ay, v[k].y, nxt[s].y);
+              nxt[s].z = fmaf(ay, v[k].z, nxt[s].z); nxt[s].w = fmaf(ay, v[k].w, nxt[s].w);
+            }
           }
+        }
+      };
+      load_group(va, 0);
+#pragma unroll 1
+      for (int u0 = 0; u0 < LPD; u0 += 2 * UB) {
+        if (!__any(u0 < cnt)) break;          // (wave-uniform) nothing left in the batch for any run of the wave
+        if (LPD > UB) load_group(vb, u0 + UB);
+        use_group(va, u0);
+        if (LPD > UB) {
+          if (u0 + 2 * UB < LPD) load_group(va, u0 + 2 * UB);
+          use_group(vb, u0 + UB);
+        }
       }
+      e_pos += LPD;
     }
-    if (step > 0 && on && chan_on) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<float4 *>(out + ((int64_t)ea * NS + s) * cseg) = cur[s];
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { cur[s] = nxt[s]; nxt[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
-  }
+    while (cur_a <= a_last) flush();
   }
 }
 
