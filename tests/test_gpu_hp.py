@@ -42,6 +42,9 @@ HP_CASES = [
     # 3-D with rows of 32 / 64 pixels and 8 | rows: the blocked tile order of the pixel-stationary kernels
     _c("hp_mdcn3d_c32_o32_rows32", M3, 2, 32, 32, (3, 16, 32), 3, seed=119),
     _c("hp_dcn3d_c64_o32_rows64_dil2", D3, 1, 64, 32, (4, 8, 64), 3, padding=2, dilation=2, bias=False, seed=120),
+    # pixel-stationary backward with 16 k-steps of output channels (C_out > 128: the register-heaviest variant)
+    _c("hp_mdcn2d_c64_o256", M2, 1, 64, 256, (9, 8), 3, seed=121),
+    _c("hp_dcn3d_c32_o200", D3, 1, 32, 200, (3, 5, 6), 3, bias=False, seed=122),
 ]
 
 # 16-bit shapes the native kernels reject in at least one direction (hp_supported): more than 256
@@ -152,6 +155,22 @@ def test_non_finite_border_pixel_is_not_read():
     # pixel (0,0) is inside the 3x3 window (zero offsets, pad 1) of output pixels (0..1, 0..1) only
     bad = ~torch.isfinite(out[0, 0])
     assert bad[:2, :2].all() and bad.sum().item() == 4
+
+
+def test_pixel_stationary_backward_is_what_runs():
+    """The shapes hp_bwd3 is written for (one conv group, one deformable group, C_in padded to a power of
+    two) take it by default -- seen through the profile slot names -- and MDCONV_HP_BWD=2 shapes keep the fused kernel."""
+    from modulated_deform_conv_amd import _capi
+    by = {c["name"]: c for c in HP_CASES}
+    for name, want in (("hp_mdcn3d_c128_o128_dil2", "hp_bwd3_kernel"), ("hp_mdcn2d_c64_o256", "hp_bwd3_kernel"),
+                       ("hp_mdcn2d_c256_o256_g32_dg4", "hp_bwd2_kernel"), ("hp_mdcn2d_c256_o64_dg8", "hp_bwd_kernel")):
+        t = make_inputs(by[name], dtype=torch.float16, device="cuda")
+        _capi.profile_enable(True)
+        _capi.profile_reset()
+        run_product(by[name], t, "auto")
+        torch.cuda.synchronize()
+        _capi.profile_enable(False)
+        assert want in _capi.profile_read(), (name, _capi.profile_read())
 
 
 def test_hp_accumulate_and_overwrite():
