@@ -290,6 +290,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"   # the image's default prints a banner on stdout
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # ... and RCCL's warnings go there too: stdout carries ONE line
         dist.init_process_group("nccl", device_id=device)
 
     from modulated_deform_conv_amd import _capi

@@ -331,7 +331,15 @@ bool get_fork(hipStream_t stream, Fork *out) {
     g_forks.erase(g_forks.begin());
   }
   Fork f;
-  if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) return false;
+  // A stream of ANOTHER priority class: HIP multiplexes the streams of one class over a few hardware queues,
+  // and once a process holds more streams (RCCL's, after init_process_group) the side stream can land on the
+  // caller's queue -- the two tails then run one after the other again (measured: 3.44 -> 3.65 ms per cfg2
+  // step under torchrun).  Priority classes have their own queues.  MDCONV_FORK_PRIO = -1 | 0 | 1 overrides.
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  static const int prio_env = getenv("MDCONV_FORK_PRIO") ? atoi(getenv("MDCONV_FORK_PRIO")) : -1;
+  const int prio = prio_env < 0 ? greatest : (prio_env > 0 ? least : 0);
+  if (hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, prio) != hipSuccess) return false;
   if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess)
     return false;

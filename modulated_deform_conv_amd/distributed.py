@@ -55,6 +55,16 @@ class FusedGradAllReduce:
 
     def __call__(self, grad_weight, grad_bias=None, async_op=False):
         grads = [g for g in (grad_weight, grad_bias) if g is not None and g.numel() > 0]
+        # RCCL, fp32 / fp64 gradients: both tensors in ONE grouped launch (ncclGroupStart / End), in place --
+        # no flat staging buffer, i.e. four copy kernels and their launches less per step (the exchange is
+        # 2.4 MB at cfg2: launch latency is all it costs)
+        if (not async_op and grads and all(g.is_cuda and g.is_contiguous() and g.dtype in (torch.float32, torch.float64)
+                                           for g in grads)
+                and hasattr(dist, "_coalescing_manager") and dist.get_backend(self.group) == "nccl"):
+            with dist._coalescing_manager(group=self.group, device=grads[0].device, async_ops=False):
+                for g in grads:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            return None
         flat = self._buffer(sum(g.numel() for g in grads), grads[0].device, grads[0].dtype)
         off = 0
         for g in grads:
