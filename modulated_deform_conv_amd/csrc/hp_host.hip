@@ -304,24 +304,40 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
                               (float *)(base + L.off_part), cnt, stream);
     profile_mark(1, false, stream);
     if (rc) return rc;
-    if (bwd3) {
-      profile_mark(2, true, stream, "hp_gemm2_kernel");
-      rc = hp_gemm2_launch(gc, hd, dtype, tc, (const int4 *)(base + L.off_tab), base + L.off_col,
-                           (float *)(base + L.off_part), stream);
-      profile_mark(2, false, stream);
-      if (rc) return rc;
-    }
-    if ((rc = hp_reduce_grad_weight(gc, hd, bwd3 ? hd.ranges_w : hd.ranges, dtype, (const float *)(base + L.off_part),
-                                    (const int4 *)(base + L.off_tab), t.grad_weight,
-                                    multi ? (float *)(base + L.off_gw32) : nullptr, first, last, stream)))
-      return rc;
-    if (b0 + bc >= g.B && (rc = record_weight_ready(stream))) return rc;
-    if ((rc = hp_csr_build(gc, dtype, tc, cnt, rowptr, base + L.off_entries, stream))) return rc;
-    profile_mark(3, true, stream, use_col2im2() ? "hp_col2im_sums_kernel" : "hp_col2im_kernel");
-    rc = use_col2im2() ? hp_col2im2(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, base + L.off_sums, stream)
-                       : hp_col2im(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, stream);
-    profile_mark(3, false, stream);
+    // Two independent tails: GEMM-2 -> split-K reduce (needs the column rows / partials) and the grad_input
+    // gather (CSR scan + fill -> partial sums -> stencil; needs the grad_col rows and the counters).  Each
+    // alone streams at ~3.6 TB/s; forked (mfma_kernels.hpp) they share the chip: cfg5 backward 5.94 -> 5.85 ms
+    // (GEMM-2 1.0 -> 1.5 ms beside the gather).  Only where GEMM-2 is its own kernel: with the fused backward
+    // the weight tail is one 27 us reduction and the fork's two cross-stream waits cost as much (cfg3).
+    hipStream_t gs = bwd3 ? fork_side_stream(stream) : nullptr;
+    const bool forked = gs != nullptr;
+    if (!forked) gs = stream;
+    auto weight_tail = [&]() -> int {
+      int r;
+      if (bwd3) {
+        profile_mark(2, true, stream, "hp_gemm2_kernel");
+        r = hp_gemm2_launch(gc, hd, dtype, tc, (const int4 *)(base + L.off_tab), base + L.off_col,
+                            (float *)(base + L.off_part), stream);
+        profile_mark(2, false, stream);
+        if (r) return r;
+      }
+      if ((r = hp_reduce_grad_weight(gc, hd, bwd3 ? hd.ranges_w : hd.ranges, dtype, (const float *)(base + L.off_part),
+                                     (const int4 *)(base + L.off_tab), t.grad_weight,
+                                     multi ? (float *)(base + L.off_gw32) : nullptr, first, last, stream)))
+        return r;
+      return last ? record_weight_ready(stream) : MDCONV_OK;
+    };
+    if (!forked && (rc = weight_tail())) return rc;
+    if ((rc = hp_csr_build(gc, dtype, tc, cnt, rowptr, base + L.off_entries, gs))) return rc;
+    profile_mark(3, true, gs, use_col2im2() ? "hp_col2im_sums_kernel" : "hp_col2im_kernel");
+    rc = use_col2im2() ? hp_col2im2(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, base + L.off_sums, gs)
+                       : hp_col2im(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, gs);
+    profile_mark(3, false, gs);
     if (rc) return rc;
+    if (forked) {
+      if ((rc = weight_tail())) return rc;
+      if ((rc = join_side_stream(stream))) return rc;
+    }
   }
   return MDCONV_OK;
 }

@@ -418,6 +418,24 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
 
 }  // namespace
 
+// fork / join for the other kernel families (hp_host.hip): side stream that waits for everything enqueued on
+// `stream` so far, or nullptr when forking is off or unavailable; join makes `stream` wait for the side stream
+hipStream_t fork_side_stream(hipStream_t stream) {
+  Fork fk;
+  if (!bwd_fork_enabled() || !get_fork(stream, &fk)) return nullptr;
+  if (hipEventRecord(fk.fork, stream) != hipSuccess || hipStreamWaitEvent(fk.side, fk.fork, 0) != hipSuccess) return nullptr;
+  return fk.side;
+}
+int join_side_stream(hipStream_t stream) {
+  Fork fk;
+  if (!get_fork(stream, &fk)) return MDCONV_ELAUNCH;
+  if (hipEventRecord(fk.join, fk.side) != hipSuccess || hipStreamWaitEvent(stream, fk.join, 0) != hipSuccess) {
+    set_error("backward join failed");
+    return MDCONV_ELAUNCH;
+  }
+  return MDCONV_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 16-bit tensors on the shape-generic backward: it scatters grad_input / grad_weight with atomics,
 // and a 16-bit atomic rounds at EVERY add (bf16: 2^-9 each).  So the call runs on fp32 copies in

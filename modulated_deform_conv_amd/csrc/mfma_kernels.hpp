@@ -17,6 +17,12 @@ int direct16_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipS
 // (include/mdconv.h: mdconv_stream_wait_weight_ready)
 int record_weight_ready(hipStream_t stream);
 
+// Two independent tails of a backward on two streams: fork_side_stream() returns a library-owned stream (own
+// hardware queue) that waits for everything enqueued on `stream` so far -- or nullptr (MDCONV_BWD_FORK=0);
+// join_side_stream() makes `stream` wait for it.  Captures into HIP graphs.
+hipStream_t fork_side_stream(hipStream_t stream);
+int join_side_stream(hipStream_t stream);
+
 // clears `bytes` (a multiple of 2) of device memory with a kernel (graph-capture friendly)
 int zero_bytes(void *p, size_t bytes, hipStream_t stream);
 
