@@ -268,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     } else
 #endif
     if (one_img) {   // scalar row base, dead pixels out of range (dropped)
-      buf_store4u(r_gcol, tail.x + oc8 * 16, 0, gq);
-      buf_store4u(r_col, tail.x + oc8 * 16, 0, cq);
+      buf_store4u_nt(r_gcol, tail.x + oc8 * 16, 0, gq);
+      buf_store4u_nt(r_col, tail.x + oc8 * 16, 0, cq);
     } else if (tail.x != kHpOob) {
       const size_t e = (size_t)tail.y * gcol_img + (tail.x >> 1) + oc8 * 8;
       *reinterpret_cast<U4 *>(gcol + e) = gq;

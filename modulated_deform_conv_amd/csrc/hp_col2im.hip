@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
 #pragma unroll
       for (int k = 0; k < UB; ++k) {
         const int src = __shfl(src_m, u0 + k, LPD);
-        v[k] = buf_load4u(r_gc, src * hd.Cp * 2 + c_voff, 0);
+        v[k] = buf_load4u_nt(r_gc, src * hd.Cp * 2 + c_voff, 0);
       }
     };
     auto use_group = [&](const U4 (&v)[UB], int u0) {

@@ -102,6 +102,19 @@ __device__ __forceinline__ void buf_store4u(rsrc_t r, int voff, int soff, const 
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 
+// streaming variants for rows that are written once / read once (aux bit 1 = nt): keeps them from evicting
+// the gathered input rows from the L2.  HP_NT = 0 builds them as plain accesses (A/B switch).
+#ifndef HP_NT
+#define HP_NT 1
+#endif
+__device__ __forceinline__ U4 buf_load4u_nt(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, HP_NT ? 2 : 0));
+}
+__device__ __forceinline__ void buf_store4u_nt(rsrc_t r, int voff, int soff, const U4 &v) {
+  typedef unsigned int u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, HP_NT ? 2 : 0);
+}
+
 // acc[j] += w * element j of the 8 packed values in v
 template <typename T> __device__ __forceinline__ void mac8(float (&acc)[8], const U4 &v, float w) {
   acc[0] = T::template mac<0>(acc[0], v.x, w); acc[1] = T::template mac<1>(acc[1], v.x, w);

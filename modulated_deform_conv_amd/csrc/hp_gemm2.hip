@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * WAVES, MB2 <= 4 ? 3 : 1) void hp_gemm2_kernel(
       const int p = item / LPP, oc = item - p * LPP;
       if (tile_ok) {
         const rsrc_t r_c = make_rsrc(colbuf + (size_t)min(lb, g.B - 1) * col_img, lb < g.B ? col_img * 2 : 0);
-        return buf_load4u(r_c, (p * Cp + oc * 8) * 2, ((tap * g.S_o + lp) * Cp) * 2);
+        return buf_load4u_nt(r_c, (p * Cp + oc * 8) * 2, ((tap * g.S_o + lp) * Cp) * 2);
       }
       int bb = lb, pp = lp + p;
       while (pp >= g.S_o) { pp -= g.S_o; ++bb; }
