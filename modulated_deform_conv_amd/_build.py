@@ -71,6 +71,25 @@ def build_variant(name, extra_flags):
     return lib
 
 
+def build_one_file_variant(name, src_basename, extra_flags):
+    """Developer aid: libmdconv_hip_<name>.so = the default objects with ONE source recompiled under extra
+    -D flags (ablation experiments that touch a single kernel file; seconds instead of a full rebuild)."""
+    build()
+    obj_dir = os.path.join(CSRC, "_obj_" + name)
+    os.makedirs(obj_dir, exist_ok=True)
+    src = os.path.join(CSRC, src_basename)
+    obj = os.path.join(obj_dir, src_basename + ".o")
+    r = subprocess.run([_hipcc()] + FLAGS + FILE_FLAGS.get(src_basename, []) + list(extra_flags) + ["-c", src, "-o", obj],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    objs = [obj if os.path.basename(o) == src_basename + ".o" else o
+            for o in sorted(glob.glob(os.path.join(OBJ, "*.o")))]
+    lib = os.path.join(HERE, "libmdconv_hip_%s.so" % name)
+    subprocess.run([_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs, check=True)
+    return lib
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))

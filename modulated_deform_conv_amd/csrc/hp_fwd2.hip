@@ -139,8 +139,9 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
       } else {
         on = on && ob < nvalid;
       }
-      if (on)
-        wr[k] = buf_load4u(r_w, lane * 16, ((tap * nchunks + ch) * hd.oblks + orange * MB + ob) * 1024);
+      // unconditional load from an out-of-range offset when the fragment is not needed (returns 0, no
+      // traffic): a conditional load into the array put wr[] in scratch (36 bytes per lane at MB = 4)
+      wr[k] = buf_load4u(r_w, on ? lane * 16 : kHpOob, on ? ((tap * nchunks + ch) * hd.oblks + orange * MB + ob) * 1024 : 0);
     }
   };
   auto w_store = [&](U4 *Ab, int ch0) {
@@ -173,7 +174,11 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     }
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) {
+#ifdef ABL_FWD_NOGATHER   // developer ablation (timing only): every corner from one cache-resident row
+      s.v[ci] = buf_load4u(r_xt, (ev[ci] & 0xff00) + lane_off, cbase2);
+#else
       s.v[ci] = buf_load4u(r_xt, ev[ci] + lane_off, cbase2);
+#endif
       s.w[ci] = __int_as_float(ev[NC + ci]);
     }
   };
@@ -184,7 +189,11 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) col[j] = 0.f;
 #pragma unroll
+#ifdef ABL_FWD_NOINTERP   // developer ablation (timing only): one corner instead of 2^ND
+    for (int ci = 0; ci < 1; ++ci) mac8<T>(col, s.v[ci], s.w[ci]);
+#else
     for (int ci = 0; ci < NC; ++ci) mac8<T>(col, s.v[ci], s.w[ci]);
+#endif
     *reinterpret_cast<U4 *>(bt_w + pg * 8 * kBtP) = pack8<T>(col);
   };
 
@@ -237,7 +246,11 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     __syncthreads();
     if (s + 1 < S) w_load(tap1, ch_lo + st1 * kStage);
     // ---- matrix phase ----
+#ifdef ABL_FWD_NOMFMA   // developer ablation (timing only): no matrix phase (and no A / B fragment reads)
+    const int nj = 0;
+#else
     const int nj = min(kStage, ch_hi - ch0);
+#endif
 #pragma unroll
     for (int j = 0; j < kStage; ++j) {
       if (j < nj) {

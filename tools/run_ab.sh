@@ -1,16 +1,20 @@
 mkdir -p gpurun_out
-rm -f gpurun_out/b18.txt
-for v in default nont default nont; do
+rm -f gpurun_out/b21.txt
+for v in default fng fni fnm fnall; do
 L=""; [ $v != default ] && L=$PWD/modulated_deform_conv_amd/libmdconv_hip_$v.so
-echo "== $v" >> gpurun_out/b18.txt
-MDCONV_LIB=$L python - >> gpurun_out/b18.txt 2>&1 <<'PY'
+echo "== $v" >> gpurun_out/b21.txt
+MDCONV_LIB=$L python - >> gpurun_out/b21.txt 2>&1 <<'PY'
 import sys, torch
 sys.path.insert(0, ".")
 import bench
-for n in ("cfg5",):
-    r = bench.time_other_config(n, "cuda")
-    print(n, r["fwd_ms"], r["bwd_ms"], r["kernels_ms"])
+wl = bench.Workload("cfg5", "cuda")
+for _ in range(3): wl.forward()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): wl.forward()
+e1.record(); torch.cuda.synchronize()
+print("cfg5 fwd %.3f ms" % (e0.elapsed_time(e1) / 10))
 PY
 done
-(timeout 600 python -m pytest tests/test_gpu_hp.py -m gpu -q -x 2>&1 | tail -3) >> gpurun_out/b18.txt 2>&1
-cat gpurun_out/b18.txt
+cat gpurun_out/b21.txt
