@@ -106,3 +106,42 @@ def test_python_surface_and_cpu_behaviour():
     assert mdc.DeformConv2dFunction._infer_shape(
         type("C", (), dict(stride=(2, 2), padding=(1, 1), dilation=(1, 1)))(), torch.empty(2, 4, 9, 7),
         torch.empty(6, 4, 3, 3)) == (2, 6, 5, 4)
+
+
+def _plan_desc(capi, nd, dtype, B, C, O, sz, G=1, DG=1, dil=1):
+    d = capi.MdconvDesc()
+    d.ndim, d.modulated, d.dtype, d.batch, d.c_in, d.c_out = nd, 1, dtype, B, C, O
+    f = lambda v, x: tuple(v) + (x,) * (3 - nd)
+    d.in_sz = (ctypes.c_int * 3)(*f(sz, 1))
+    d.k_sz = (ctypes.c_int * 3)(*f((3,) * nd, 1))
+    d.stride = (ctypes.c_int * 3)(1, 1, 1)
+    d.pad = (ctypes.c_int * 3)(*f((dil,) * nd, 0))
+    d.dil = (ctypes.c_int * 3)(*f((dil,) * nd, 1))
+    d.groups, d.dgroups, d.in_step, d.with_bias = G, DG, 64, 0
+    return d
+
+
+def test_workspace_plan_and_layout_query_without_gpu(capi):
+    """Host planning only (no device needed): the workspace covers the buffers DESIGN.md section 3 names, and
+    the per-direction channels-last query (include/mdconv.h: mdconv_input_layout_supported) separates shapes the
+    native 16-bit forward takes from those its backward takes (a forward that consumed the layout
+    in place must not be followed by a backward that raises)."""
+    L = capi.lib()
+    ws = lambda d, bwd: L.mdconv_workspace_bytes(ctypes.byref(d), bwd)
+    cl = lambda d, bwd: L.mdconv_input_layout_supported(ctypes.byref(d), 1, bwd)
+    cfg2 = _plan_desc(capi, 2, capi.F32, 32, 256, 256, (56, 56))
+    n, K = 32 * 56 * 56, 9
+    assert ws(cfg2, 0) == 256 * 256 * K * 4                                  # packed weights only: no column buffer
+    assert ws(cfg2, 1) >= n * K * 256 * 4 and ws(cfg2, 1) < 1.5 * n * K * 256 * 4   # grad_col rows + lists + tables
+    assert cl(cfg2, 0) == 0 and cl(cfg2, 1) == 0                             # fp32: reference layout only
+    cfg5 = _plan_desc(capi, 3, capi.F16, 8, 128, 128, (16, 64, 64), dil=2)
+    rows = 8 * 27 * 16 * 64 * 64 * 128 * 2                                   # one set of 16-bit rows [b][tap][pix][c]
+    assert 2 * rows < ws(cfg5, 1) < 2.5 * rows                               # grad_col rows + column rows + sums + lists
+    assert cl(cfg5, 0) == 1 and cl(cfg5, 1) == 1
+    wide = _plan_desc(capi, 2, capi.BF16, 2, 512, 64, (8, 8))                # 16 channel blocks: forward only
+    assert cl(wide, 0) == 1 and cl(wide, 1) == 0 and ws(wide, 1) > 0          # backward: fp32 copies on the fp32 kernels
+    dg16 = _plan_desc(capi, 2, capi.F16, 2, 64, 64, (8, 8), DG=4)            # deformable groups of 16 channels
+    assert cl(dg16, 0) == 1 and cl(dg16, 1) == 0 and ws(dg16, 1) > 0          # backward: shape-generic kernels on fp32 copies
+    assert L.mdconv_input_layout_supported(ctypes.byref(cfg5), 0, 1) == 1    # NCHW always
+    assert L.mdconv_input_layout_supported(ctypes.byref(cfg5), 7, 1) == 0
+    assert capi.lib().mdconv_profile_name(9) == b""
