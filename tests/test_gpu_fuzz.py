@@ -73,3 +73,53 @@ def test_fuzz_exercises_the_matrix_core_path():
     bwd = sum(1 for p in _PATHS if p[1] == "mfma")
     fwd = sum(1 for p in _PATHS if p[0] == "mfma")
     assert bwd >= 30 and fwd >= 20, (fwd, bwd)
+
+
+def _random_hp_case(seed):
+    """Random shapes for the native 16-bit kernels: channel counts around the 32-channel blocks (ragged
+    ones are padded), conv groups, deformable groups of 32 / 64 channels, odd extents and batch tails --
+    hp_bwd3 + hp_gemm2 (one group, power-of-two padded C_in), hp_bwd2, hp_bwd, the two-pass gathers."""
+    r = random.Random(1000 + seed)
+    nd = r.choice([2, 2, 3])
+    modulated = r.random() < 0.6
+    op = {(2, False): D2, (2, True): M2, (3, False): D3, (3, True): M3}[(nd, modulated)]
+    dg = r.choice([1, 1, 1, 2, 4, 8])
+    if dg > 1:
+        C = dg * r.choice([32, 64])
+        if C > 256:
+            C = 256
+            dg = 256 // r.choice([32, 64])
+        groups = r.choice([1, 2]) if C % 2 == 0 else 1
+    else:
+        C = r.choice([8, 24, 32, 40, 64, 96, 128, 136, 256])
+        groups = r.choice([1, 1, 1, 2, 4, 8])
+        while C % groups:
+            groups //= 2
+    O = r.choice([8, 24, 32, 48, 64, 100, 128, 200, 256])
+    O = (O + groups - 1) // groups * groups
+    k = r.choice([1, 2, 3, 3]) if nd == 2 else r.choice([1, 2, 3])
+    stride = r.choice([1, 1, 2])
+    dil = r.choice([1, 1, 2])
+    pad = r.choice([0, 1, dil * (k - 1) // 2 + (1 if k > 1 else 0)])
+    lo = dil * (k - 1) + 1
+    size = tuple(r.randint(max(lo, 3), 12 if nd == 2 else 6) for _ in range(nd))
+    size = size[:-1] + (max(size[-1], 2),)
+    return _c("hpfuzz%d" % seed, op, r.choice([1, 2, 3]), C, O, size, k, stride=stride, padding=pad, dilation=dil,
+              groups=groups, dgroups=dg, in_step=64, bias=r.random() < 0.5, tier="medium", seed=1500 + seed,
+              offset_scale=r.choice([0.5, 1.0, 3.0]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("seed", range(24))
+def test_16bit_random_shapes_against_the_oracle(seed, dtype):
+    if dtype == torch.bfloat16 and seed % 3:
+        pytest.skip("bf16: every third shape")
+    case = _random_hp_case(seed)
+    t = make_inputs(case, dtype=dtype, device="cuda")
+    out, grads, _ = run_product(case, t, "auto")
+    want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
+    tol = 1e-2 if dtype == torch.float16 else 4e-2
+    assert_close("output", out.float(), want_out, tol)
+    for k, v in grads.items():
+        if v is not None and want[k] is not None:
+            assert_close(k, v.float(), want[k], tol)
