@@ -239,15 +239,18 @@ def test_weight_ready_event_orders_a_side_stream():
         assert_close("grad_input", gi, ref[0], 1e-5)
 
 
-@pytest.mark.parametrize("name", ["cfg2s_mdcn2d_c64_28x28_b4", "cfg4s_dcn3d_c16_12cubed_b2",
-                                  "mfma_mdcn2d_g4_dg2_c128_o64"])
-def test_hip_graph_capture_and_replay(name):
-    """Forward + backward are a plain sequence of kernel launches on the caller's stream (no
-    memset nodes, no host synchronisation), so they capture into a HIP graph; the replay must
-    reproduce the eager results."""
+@pytest.mark.parametrize("name, dtype", [
+    ("cfg2s_mdcn2d_c64_28x28_b4", torch.float32), ("cfg4s_dcn3d_c16_12cubed_b2", torch.float32),
+    ("mfma_mdcn2d_g4_dg2_c128_o64", torch.float32),
+    ("cfg5s_mdcn3d_c16_dil2", torch.float16),       # hp_bwd3 + hp_gemm2 + two-pass gather, tails forked
+    ("mfma_mdcn2d_g4_dg2_c128_o64", torch.float16)])   # hp_bwd2 (fused)
+def test_hip_graph_capture_and_replay(name, dtype):
+    """Forward + backward are a plain sequence of kernel launches on the caller's stream and the library's
+    forked side stream (event fork / join, no memset nodes, no host synchronisation), so they capture into a
+    HIP graph; the replay must reproduce the eager results."""
     from tests.util import run_product
     case = CASE_BY_NAME[name]
-    t = make_inputs(case, device="cuda")
+    t = make_inputs(case, dtype=dtype, device="cuda")
     ref_out, ref_g, paths = run_product(case, t, "auto")
     assert paths[1] == "mfma"
     torch.cuda.synchronize()
@@ -261,10 +264,11 @@ def test_hip_graph_capture_and_replay(name):
     for _ in range(2):
         graph.replay()
     torch.cuda.synchronize()
-    assert_close("output", out, ref_out, 1e-6)
+    tol = 1e-5 if dtype == torch.float32 else 2e-3   # grad_input: list order depends on integer-atomic arrival
+    assert_close("output", out.float(), ref_out.float(), 1e-6)
     for k, v in g.items():
         if v is not None and ref_g[k] is not None:
-            assert_close(k, v, ref_g[k], 1e-5)
+            assert_close(k, v.float(), ref_g[k].float(), tol, 4 * tol)
 
 
 @pytest.mark.parametrize("cls_name, nd, modulated, kw", [
