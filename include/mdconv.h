@@ -141,19 +141,6 @@ int mdconv_input_layout_supported(const mdconv_desc *d, int layout, int backward
 int mdconv_stream_wait_weight_ready(void *stream);
 int mdconv_stream_wait_weight_ready_on(void *stream, void *producer_stream);
 
-/* Side convolutions of the reference's *Pack modules (modulated_deform_conv.py:730-839: `self.conv_offset(x)`
- * and, for the modulated ones, `self.conv_mask(x)`, two framework convolutions per call) as ONE launch of this
- * library's forward kernels in plain-convolution mode: `d` describes the MAIN deformable convolution; the side
- * convolutions have its kernel size, stride and padding, dilation 1 (the reference does not forward it,
- * :734-738) and a bias each; weight_offset is [DG*nd*K, C_in, k...], weight_mask [DG*K, C_in, k...] (NULL with
- * mask == NULL for the non-modulated packs).  offset / mask are written as two contiguous tensors in the
- * layouts the entry points below consume.  MDCONV_EUNSUPPORTED when the shape would need batch chunks or
- * fp32 copies (callers then use their framework's convolution). */
-size_t mdconv_side_conv_workspace_bytes(const mdconv_desc *d, int with_mask);
-int mdconv_side_conv_forward(const mdconv_desc *d, const void *input, const void *weight_offset,
-                             const void *bias_offset, const void *weight_mask, const void *bias_mask,
-                             void *offset, void *mask, void *workspace, size_t workspace_bytes, void *stream);
-
 /* --- replaces deform_conv2d_forward_cuda (deformable_conv.cu:117-123) ---------------------- */
 int mdconv_deform_conv2d_forward(const mdconv_desc *d, const void *input, const void *weight,
                                  const void *bias, const void *offset, void *output,

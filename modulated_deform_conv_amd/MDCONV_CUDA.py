@@ -158,63 +158,6 @@ def _forward(nd, modulated, fn_name, input, weight, bias, offset, mask, output, 
     return output
 
 
-def side_conv_forward(input, weight_offset, bias_offset, weight_mask, bias_mask, kernel_size, stride, padding,
-                      deformable_group):
-    """Extension of the module surface (not one of the reference's eight exports): the side convolutions of
-    the reference's *Pack modules (modulated_deform_conv.py:779-783, `self.conv_offset(x)` / `self.conv_mask(x)`)
-    in ONE launch of the library's forward kernels in plain-convolution mode (include/mdconv.h:
-    mdconv_side_conv_forward).  Returns (offset, mask) -- mask is None when `weight_mask` is None -- as two
-    contiguous tensors, or None when the library does not take the shape (the caller then runs its own
-    convolutions, like the reference)."""
-    nd = input.dim() - 2
-    tensors = dict(input=input, weight_offset=weight_offset, bias_offset=bias_offset)
-    if weight_mask is not None:
-        tensors.update(weight_mask=weight_mask, bias_mask=bias_mask)
-    for name, t in tensors.items():
-        if not t.is_cuda or not t.is_contiguous() or t.dtype != input.dtype or t.device != input.device:
-            return None
-    if input.dtype not in _DTYPES:
-        return None
-    K = _prod(kernel_size)
-    n_off, n_mask = deformable_group * nd * K, deformable_group * K
-    if tuple(weight_offset.shape) != (n_off, input.shape[1]) + tuple(kernel_size) or bias_offset.numel() != n_off:
-        return None
-    if weight_mask is not None and (tuple(weight_mask.shape) != (n_mask, input.shape[1]) + tuple(kernel_size)
-                                    or bias_mask.numel() != n_mask):
-        return None
-    L = _capi.lib()
-    d = _capi.MdconvDesc()
-    d.ndim, d.modulated, d.dtype = nd, int(weight_mask is not None), _DTYPES[input.dtype]
-    d.batch, d.c_in, d.c_out = input.shape[0], input.shape[1], n_off    # c_out is recomputed by the library
-    fill = lambda v, f: tuple(int(x) for x in v) + (f,) * (3 - nd)
-    d.in_sz = (ctypes.c_int * 3)(*fill(input.shape[2:], 1))
-    d.k_sz = (ctypes.c_int * 3)(*fill(kernel_size, 1))
-    d.stride = (ctypes.c_int * 3)(*fill(stride, 1))
-    d.pad = (ctypes.c_int * 3)(*fill(padding, 0))
-    d.dil = (ctypes.c_int * 3)(1, 1, 1)
-    d.groups, d.dgroups, d.in_step, d.with_bias = 1, int(deformable_group), 64, 1
-    osz = _out_shape(d, nd)
-    if min(osz) <= 0:
-        return None
-    with torch.cuda.device(input.device):
-        offset = torch.empty((d.batch, n_off) + osz, dtype=input.dtype, device=input.device)
-        mask = torch.empty((d.batch, n_mask) + osz, dtype=input.dtype, device=input.device) if weight_mask is not None else None
-        ws_bytes = L.mdconv_side_conv_workspace_bytes(ctypes.byref(d), int(mask is not None))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device) if ws_bytes else None
-        null = ctypes.c_void_p(0)
-        rc = L.mdconv_side_conv_forward(
-            ctypes.byref(d), _ptr(input), _ptr(weight_offset), _ptr(bias_offset),
-            _ptr(weight_mask) if mask is not None else null, _ptr(bias_mask) if mask is not None else null,
-            _ptr(offset), _ptr(mask) if mask is not None else null,
-            ctypes.c_void_p(ws.data_ptr() if ws is not None else 0), ctypes.c_size_t(ws_bytes),
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    if rc == -5:      # MDCONV_EUNSUPPORTED
-        return None
-    if rc != 0:
-        raise RuntimeError("mdconv_side_conv_forward failed (%d): %s" % (rc, _capi.last_error()))
-    return offset, mask
-
-
 # --------------------------------------------------------------------------------- 2-D, DCNv1
 def deform_conv2d_forward_cuda(input, weight, bias, offset, output, kernel_h, kernel_w, stride_h,
                                stride_w, pad_h, pad_w, dilation_h, dilation_w, group,

@@ -17,7 +17,7 @@ EXPORTS = (
     "mdconv_set_path", "mdconv_last_path", "mdconv_last_kernels",
     "mdconv_profile_enable", "mdconv_profile_read", "mdconv_profile_reset", "mdconv_profile_name",
     "mdconv_stream_wait_weight_ready", "mdconv_stream_wait_weight_ready_on", "mdconv_set_accumulate", "mdconv_set_input_layout",
-    "mdconv_input_layout_supported", "mdconv_side_conv_workspace_bytes", "mdconv_side_conv_forward",
+    "mdconv_input_layout_supported",
     "mdconv_deform_conv2d_forward", "mdconv_deform_conv2d_backward",
     "mdconv_modulated_deform_conv2d_forward", "mdconv_modulated_deform_conv2d_backward",
     "mdconv_deform_conv3d_forward", "mdconv_deform_conv3d_backward",
@@ -69,10 +69,8 @@ def lib():
         L.mdconv_stream_wait_weight_ready_on.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.mdconv_last_kernels.restype = ctypes.c_int
         L.mdconv_input_layout_supported.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-        L.mdconv_side_conv_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
         for name in EXPORTS[11:]:
             getattr(L, name).restype = ctypes.c_int
-        L.mdconv_side_conv_workspace_bytes.restype = ctypes.c_size_t
         if L.mdconv_abi_version() != 1:
             raise ImportError("libmdconv_hip.so ABI version mismatch")
         _lib = L

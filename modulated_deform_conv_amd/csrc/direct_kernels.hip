@@ -61,7 +61,7 @@ __device__ __forceinline__ void load_tap(const Geom &g, const T *offset, const T
   A delta[ND];
   const int64_t obase = ((int64_t)(b * g.DG + dg) * (ND * g.K) + ND * tap) * g.S_o + pix;
 #pragma unroll
-  for (int a = 0; a < ND; ++a) delta[a] = g.side ? (A)0 : (A)ld(offset + obase + (int64_t)a * g.S_o);
+  for (int a = 0; a < ND; ++a) delta[a] = (A)ld(offset + obase + (int64_t)a * g.S_o);
   int t[ND];
   tap_coords<ND>(g, tap, t);
   make_tap<ND, A>(g, o, t, delta, bwd, tc);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kThreads) void direct_fwd_kernel(Geom g, int CC, co
       const int t = i % TO;
       const int r = i / TO;  // cc*K + tap
       const int oc = o0 + t;
-      Ws[i] = (oc < g.Og) ? (A)ld(weight_row(g, weight, grp * g.Og + oc) + (int64_t)c0 * g.K + r) : (A)0;
+      Ws[i] = (oc < g.Og) ? (A)ld(weight + ((int64_t)(grp * g.Og + oc) * g.Cg + c0) * g.K + r) : (A)0;
     }
     __syncthreads();
     for (int tap = 0; tap < g.K; ++tap) {
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(kThreads) void direct_fwd_kernel(Geom g, int CC, co
       const int oc = o0 + t;
       if (oc < g.Og) {
         const int och = grp * g.Og + oc;
-        const A bv = g.with_bias ? (A)ld(bias_of(g, bias, och)) : (A)0;
-        st(out_plane(g, output, b, och) + pix, acc[t] + bv);
+        const A bv = g.with_bias ? (A)ld(bias + och) : (A)0;
+        st(output + (int64_t)(b * g.O + och) * g.S_o + pix, acc[t] + bv);
       }
     }
   }

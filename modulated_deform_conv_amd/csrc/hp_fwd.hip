@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void hp_fwd_kernel(
     const int64_t seg = (int64_t)b * g.DG + dg;
     const int64_t ob = (seg * (ND * g.K) + ND * tap) * g.S_o + pix;
 #pragma unroll
-    for (int a = 0; a < ND; ++a) dl[a] = g.side ? 0.f : T::ldf(offset + ob + (int64_t)a * g.S_o);
+    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(offset + ob + (int64_t)a * g.S_o);
     if (MOD) ml = T::ldf(mask + (seg * g.K + tap) * g.S_o + pix);
     pf_tap = tap;
     pf_dg = dg;
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void hp_fwd_kernel(
       for (int r = 0; r < 16; ++r) {
         const int o = (orange * MB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (o < g.O) {
-          const float bv = g.with_bias ? T::ldf(bias_of(g, bias, o)) : 0.f;
-          T::stf(out_plane(g, output, b, o) + pix, acc[ob][r] + bv);
+          const float bv = g.with_bias ? T::ldf(bias + o) : 0.f;
+          T::stf(output + ((int64_t)b * g.O + o) * g.S_o + pix, acc[ob][r] + bv);
         }
       }
   }

@@ -223,7 +223,6 @@ static bool fwd2_rows_align(const Geom &g, const HpDims &hd) {
 int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
   const int Bc = chunk_batch(g, hp_dims(g), false);
   if (Bc <= 0) { set_error("hp_forward: no plan"); return MDCONV_EUNSUPPORTED; }
-  if (g.side && Bc < g.B) { set_error("side convolution: shape needs batch chunks"); return MDCONV_EUNSUPPORTED; }
   const Geom g0 = chunk_geom(g, Bc);
   const HpDims hd0 = hp_dims(g0);
   const FwdLayout L = fwd_layout(g0, hd0);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void hp_pack_fwd_kernel(Geom g, HpDims hd,
     for (int j = 0; j < 8; ++j) {
       const int c = cb + j;
       e[j] = (o < g.O && c < g.C && o / g.Og == c / g.Cg)
-                 ? weight_row(g, w, o)[(int64_t)(c % g.Cg) * g.K + tap] : (unsigned short)0;
+                 ? w[((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap] : (unsigned short)0;
     }
     U4 v;
     v.x = e[0] | ((u32)e[1] << 16); v.y = e[2] | ((u32)e[3] << 16);

@@ -238,58 +238,6 @@ static int run_forward(const mdconv_desc *d, int nd, int modulated, Tensors t, v
   return direct_forward(g, d->dtype, t, s);
 }
 
-// Side convolutions of the *Pack modules as ONE launch of the forward kernels in plain-convolution mode
-// (Geom::side): conv_offset (and conv_mask) have the main convolution's kernel / stride / padding, dilation 1
-// (the reference does not forward it: modulated_deform_conv.py:734-738, 759-770) and a bias each.
-static int side_geom(const mdconv_desc *d, int with_mask, Geom *g) {
-  if (!d) { set_error("descriptor is NULL"); return MDCONV_ENULL; }
-  mdconv_desc s = *d;
-  int K = 1;
-  for (int a = 0; a < d->ndim && a < 3; ++a) K *= d->k_sz[a];
-  const int n_off = d->dgroups * d->ndim * K, n_mask = with_mask ? d->dgroups * K : 0;
-  s.c_out = n_off + n_mask;
-  s.groups = s.dgroups = 1;
-  s.modulated = 0;
-  s.with_bias = 1;
-  for (int a = 0; a < 3; ++a) s.dil[a] = 1;
-  int rc = fill_geom(&s, g);
-  if (rc) return rc;
-  g->side = 1;
-  g->o_split = with_mask ? n_off : 0;
-  return MDCONV_OK;
-}
-
-static int run_side_conv(const mdconv_desc *d, const void *input, const void *w_off, const void *b_off,
-                         const void *w_mask, const void *b_mask, void *offset_out, void *mask_out, void *ws,
-                         size_t ws_bytes, void *stream) {
-  g_err[0] = 0;
-  const int with_mask = mask_out != nullptr;
-  Geom g;
-  int rc = side_geom(d, with_mask, &g);
-  if (rc) return rc;
-  if ((rc = require(input, "input")) || (rc = require(w_off, "conv_offset weight")) ||
-      (rc = require(b_off, "conv_offset bias")) || (rc = require(offset_out, "offset")))
-    return rc;
-  if (with_mask && ((rc = require(w_mask, "conv_mask weight")) || (rc = require(b_mask, "conv_mask bias")))) return rc;
-  g.weight2 = w_mask; g.bias2 = b_mask; g.output2 = mask_out;
-  Tensors t = {};
-  t.input = input; t.weight = w_off; t.bias = b_off; t.output = offset_out;
-  hipStream_t s = (hipStream_t)stream;
-  const int path = current_path();
-  if (path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, false)) {
-    if ((rc = check_ws(ws, ws_bytes, hp_workspace_bytes(g, d->dtype, false)))) return rc;
-    g_last_path = MDCONV_PATH_MFMA; g_last_kernels = MDCONV_KERNELS_HP;
-    return hp_forward(g, d->dtype, t, ws, s);
-  }
-  if (path != MDCONV_PATH_DIRECT && d->dtype == MDCONV_F32 && mfma_supported(g, d->dtype, false)) {
-    if ((rc = check_ws(ws, ws_bytes, mfma_workspace_bytes(g, d->dtype, false)))) return rc;
-    g_last_path = MDCONV_PATH_MFMA; g_last_kernels = MDCONV_KERNELS_F32;
-    return mfma_forward(g, d->dtype, t, ws, s);
-  }
-  g_last_path = MDCONV_PATH_DIRECT; g_last_kernels = MDCONV_KERNELS_DIRECT;
-  return direct_forward(g, d->dtype, t, s);
-}
-
 static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, void *ws,
                         size_t ws_bytes, void *stream) {
   g_err[0] = 0;
@@ -454,22 +402,6 @@ int mdconv_input_layout_supported(const mdconv_desc *d, int layout, int backward
   if (layout == MDCONV_LAYOUT_NCHW) return 1;
   if (layout != MDCONV_LAYOUT_CHANNELS_LAST) return 0;
   return current_path() != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, backward != 0) && g.C % 32 == 0;
-}
-
-size_t mdconv_side_conv_workspace_bytes(const mdconv_desc *d, int with_mask) {
-  Geom g;
-  if (side_geom(d, with_mask, &g)) return 0;
-  if (current_path() == MDCONV_PATH_DIRECT) return 0;
-  if (hp_supported(g, d->dtype, false)) return hp_workspace_bytes(g, d->dtype, false);
-  if (d->dtype == MDCONV_F32 && mfma_supported(g, d->dtype, false)) return mfma_workspace_bytes(g, d->dtype, false);
-  return 0;
-}
-
-int mdconv_side_conv_forward(const mdconv_desc *d, const void *input, const void *weight_offset,
-                             const void *bias_offset, const void *weight_mask, const void *bias_mask,
-                             void *offset, void *mask, void *workspace, size_t workspace_bytes, void *stream) {
-  return run_side_conv(d, input, weight_offset, bias_offset, weight_mask, bias_mask, offset, mask, workspace,
-                       workspace_bytes, stream);
 }
 
 int mdconv_set_accumulate(int on) {

@@ -35,27 +35,7 @@ struct Geom {
   int acc_data, acc_w;
   // 1 = `input` is channels-last [B, spatial..., C] (mdconv_set_input_layout; 16-bit kernels only)
   int in_cl;
-  // Side convolutions of the *Pack modules (mdconv_side_conv_forward; reference modulated_deform_conv.py:
-  // 779-783): the forward kernels run as a PLAIN convolution (side = 1: no offset tensor, every offset 0) whose
-  // output channels [0, o_split) and [o_split, O) have their own weight / bias / output tensors -- conv_offset
-  // and conv_mask in one launch, each result contiguous.  o_split = 0: one tensor of each kind, as usual.
-  int side, o_split;
-  const void *weight2, *bias2;
-  void *output2;
 };
-
-// row `o` of the weight [O][C/G][K], plane (b, o) of the output [B][O][S_o], bias of o -- through the split
-template <typename T> __device__ __forceinline__ const T *weight_row(const Geom &g, const T *w, int o) {
-  return (g.o_split && o >= g.o_split) ? (const T *)g.weight2 + (int64_t)(o - g.o_split) * g.Cg * g.K
-                                       : w + (int64_t)o * g.Cg * g.K;
-}
-template <typename T> __device__ __forceinline__ T *out_plane(const Geom &g, T *out, int b, int o) {
-  if (g.o_split && o >= g.o_split) return (T *)g.output2 + ((int64_t)b * (g.O - g.o_split) + (o - g.o_split)) * g.S_o;
-  return out + ((int64_t)b * (g.o_split ? g.o_split : g.O) + o) * g.S_o;
-}
-template <typename T> __device__ __forceinline__ const T *bias_of(const Geom &g, const T *bias, int o) {
-  return (g.o_split && o >= g.o_split) ? (const T *)g.bias2 + (o - g.o_split) : bias + o;
-}
 
 template <typename T> struct Acc { using type = float; };
 template <> struct Acc<double> { using type = double; };

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
     if (tid < BN) {
       const int64_t ob = ((int64_t)b_s * (ND * g.K) + ND * tap) * g.S_o + pix_s;
 #pragma unroll
-      for (int a = 0; a < ND; ++a) dl[a] = g.side ? 0.f : offset[ob + (int64_t)a * g.S_o];
+      for (int a = 0; a < ND; ++a) dl[a] = offset[ob + (int64_t)a * g.S_o];
       if (MOD) ml = mask[((int64_t)b_s * g.K + tap) * g.S_o + pix_s];
     }
   };
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
         const int ol = o0 + wm0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (ol < g.Og) {
           const int och = grp * g.Og + ol;
-          const float bv = g.with_bias ? *bias_of(g, bias, och) : 0.f;
-          out_plane(g, output, b_e, och)[pix_e] = acc[mb][r] + bv;
+          const float bv = g.with_bias ? bias[och] : 0.f;
+          output[(int64_t)(b_e * g.O + och) * g.S_o + pix_e] = acc[mb][r] + bv;
         }
       }
   }

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(Geom g, PackDims pd,
     const int o = mblk * 32 + (lane & 31);
     const int c = cchunk * kBK + 8 * q + 4 * (lane >> 5) + s;
     const float v = (o < g.Og && c < g.Cg)
-                        ? weight_row(g, w, grp * g.Og + o)[(int64_t)c * g.K + tap] : 0.f;
+                        ? w[((int64_t)(grp * g.Og + o) * g.Cg + c) * g.K + tap] : 0.f;
     wp[i] = v;
     if (wq) wq[(((int64_t)grp * g.K + tap) * pd.Ogp + o) * pd.Cgp + c] = v;
   }
@@ -513,10 +513,6 @@ size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
 int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
   Plan p;
   if (!make_plan(g, dtype, false, &p)) { set_error("mfma_forward: no plan"); return MDCONV_EUNSUPPORTED; }
-  if (g.side && (p.half_io || p.Bc < g.B)) {   // split outputs: one chunk, native dtype only
-    set_error("side convolution: shape needs batch chunks or fp32 copies");
-    return MDCONV_EUNSUPPORTED;
-  }
   char *base = (char *)ws;
   const size_t es = p.half_io ? 2 : 4;
   const int nc_off = g.DG * g.nd * g.K, nc_m = g.DG * g.K;

@@ -229,45 +229,6 @@ class ModulatedDeformConv3d(_DeformConvNd):
         return modulated_deform_conv3d(x, offset, mask, *self._conv_args())
 
 
-class _SideConvFunction(Function):
-    """conv_offset (and conv_mask) of a *Pack module through the library's own forward kernels in
-    plain-convolution mode: one launch, two contiguous results, no concatenated weights and no slice
-    copies (MDCONV_CUDA.side_conv_forward).  Backward = the framework's convolution backward of each of
-    the two convolutions, as for the reference's two nn.ConvNd calls."""
-
-    @staticmethod
-    def forward(ctx, x, w_off, b_off, w_mask, b_mask, kernel_size, stride, padding, deformable_groups):
-        res = MDCONV_CUDA.side_conv_forward(x, w_off, b_off, w_mask, b_mask, kernel_size, stride, padding,
-                                            deformable_groups)
-        if res is None:
-            raise _SideConvUnsupported()
-        ctx.save_for_backward(x, w_off, w_mask)
-        ctx.stride, ctx.padding = tuple(stride), tuple(padding)
-        offset, mask = res
-        return (offset, mask) if mask is not None else offset
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, *grads):
-        x, w_off, w_mask = ctx.saved_tensors
-        nd = x.dim() - 2
-        conv_bwd = torch.ops.aten.convolution_backward
-        need = (ctx.needs_input_grad[0], True, True)
-        gx, gw_off, gb_off = conv_bwd(grads[0].contiguous(), x, w_off, [w_off.shape[0]], list(ctx.stride), list(ctx.padding),
-                                      [1] * nd, False, [0] * nd, 1, list(need))
-        gw_mask = gb_mask = None
-        if w_mask is not None:
-            gx2, gw_mask, gb_mask = conv_bwd(grads[1].contiguous(), x, w_mask, [w_mask.shape[0]], list(ctx.stride),
-                                             list(ctx.padding), [1] * nd, False, [0] * nd, 1, list(need))
-            if gx is not None:
-                gx = gx + gx2
-        return gx, gw_off, gb_off, gw_mask, gb_mask, None, None, None, None
-
-
-class _SideConvUnsupported(Exception):
-    pass
-
-
 class _PackMixin:
     """Adds the offset (and mask) producing convolutions (reference :730-839).
 
@@ -276,8 +237,6 @@ class _PackMixin:
     """
 
     def _make_side_convs(self):
-        import os
-        self.own_side_conv = os.environ.get("MDCONV_PACK_SIDE", "") == "own"
         conv = nn.Conv2d if self._nd == 2 else nn.Conv3d
         K = math.prod(self.kernel_size)
         self.conv_offset = conv(self.in_channels, self.deformable_groups * self._nd * K,
@@ -315,48 +274,30 @@ def _make_pack(base, name):
                 and not torch.nn.modules.module._global_forward_hooks
                 and not torch.nn.modules.module._global_forward_pre_hooks)
 
-    def _side(self, x):
-        """offset (, mask) of x.  The modules are CALLED, exactly like the reference (:779-783), unless
-        conv_offset / conv_mask are plain, hook-free convolutions of identical geometry (what the constructor
-        builds); then, two measured fast paths (MI355X, cfg2 shape fp32: two framework
-        convolutions 0.34 ms):
-          * default: conv_offset and conv_mask as ONE framework convolution over the concatenated weights,
-            the two halves copied out (0.23 ms; fp16 0.13 ms);
-          * `own_side_conv = True` (or MDCONV_PACK_SIDE=own): ONE launch of this library's forward kernels in
-            plain-convolution mode (MDCONV_CUDA.side_conv_forward): no concatenated weights, no copies, two
-            contiguous results -- 0.46 ms in fp32 (a 27-row output uses 42 % of the 64-row matrix tile), 0.14 ms
-            in fp16.  It is the path without any framework convolution in the forward, not the fastest one."""
-        co, cm = self.conv_offset, getattr(self, "conv_mask", None)
-        conv_cls = nn.Conv2d if self._nd == 2 else nn.Conv3d
-        plain = _plain(co, conv_cls) and (cm is None or (
-            _plain(cm, conv_cls) and co.stride == cm.stride and co.padding == cm.padding and co.dilation == cm.dilation
-            and co.kernel_size == cm.kernel_size and co.weight.dtype == cm.weight.dtype))
-        one = (1,) * self._nd
-        if (plain and self.own_side_conv and x.is_cuda and co.dilation == one and co.weight.dtype == x.dtype
-                and not torch.is_autocast_enabled("cuda")):
-            try:
-                res = _SideConvFunction.apply(x.contiguous(), co.weight, co.bias,
-                                              cm.weight if cm is not None else None, cm.bias if cm is not None else None,
-                                              co.kernel_size, co.stride, co.padding, self.deformable_groups)
-                return res if cm is not None else (res, None)
-            except _SideConvUnsupported:
-                pass
-        if plain and cm is not None:
-            conv = torch.nn.functional.conv2d if self._nd == 2 else torch.nn.functional.conv3d
-            y = conv(x, torch.cat((co.weight, cm.weight)), torch.cat((co.bias, cm.bias)),
-                     co.stride, co.padding, co.dilation)
-            n_off = co.out_channels
-            return y[:, :n_off].contiguous(), y[:, n_off:].contiguous()
-        return co(x), (cm(x) if cm is not None else None)
-
     if base._modulated:
         def forward(self, x):
-            offset, mask = self._side(x)
-            return base.forward(self, x, offset, mask)
+            # ONE side convolution for offset and mask: the two parameter
+            # sets stay separate modules (state_dict keys conv_offset.* / conv_mask.* as in the
+            # reference) and are concatenated along the output channels, so the input is read once
+            # and one library launch replaces two.  Same numbers as two convolutions.  Only when
+            # both are plain convolutions of identical geometry; otherwise the modules are CALLED,
+            # exactly like the reference (:779-783), so hooks / parametrisations / replaced
+            # submodules keep working.
+            co, cm = self.conv_offset, self.conv_mask
+            conv_cls = nn.Conv2d if self._nd == 2 else nn.Conv3d
+            if (_plain(co, conv_cls) and _plain(cm, conv_cls) and co.stride == cm.stride
+                    and co.padding == cm.padding and co.dilation == cm.dilation
+                    and co.kernel_size == cm.kernel_size and co.weight.dtype == cm.weight.dtype):
+                conv = torch.nn.functional.conv2d if self._nd == 2 else torch.nn.functional.conv3d
+                y = conv(x, torch.cat((co.weight, cm.weight)), torch.cat((co.bias, cm.bias)),
+                         co.stride, co.padding, co.dilation)
+                n_off = co.out_channels
+                return base.forward(self, x, y[:, :n_off].contiguous(), y[:, n_off:].contiguous())
+            return base.forward(self, x, co(x), cm(x))
     else:
         def forward(self, x):
-            return base.forward(self, x, self._side(x)[0])
-    return type(name, (_PackMixin, base), {"__init__": __init__, "forward": forward, "_side": _side})
+            return base.forward(self, x, self.conv_offset(x))
+    return type(name, (_PackMixin, base), {"__init__": __init__, "forward": forward})
 
 
 DeformConv2dPack = _make_pack(DeformConv2d, "DeformConv2dPack")

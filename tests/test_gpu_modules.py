@@ -89,19 +89,15 @@ def test_pack_module_runs():
     assert m.conv_offset.weight.grad is not None and m.conv_mask.weight.grad is not None
 
 
-@pytest.mark.parametrize("own", [False, True], ids=["framework", "own"])
 @pytest.mark.parametrize("nd", [2, 3])
-def test_pack_fused_side_conv_equals_two_convs(nd, own):
-    """The Pack modules run conv_offset and conv_mask as ONE convolution -- the framework's over concatenated
-    weights (default) or ONE launch of the library's own forward kernels in plain-convolution mode
-    (own_side_conv); output and every parameter gradient must equal the reference formulation with two
-    framework convolutions (reference :755-785)."""
+def test_pack_fused_side_conv_equals_two_convs(nd):
+    """The Pack modules run conv_offset and conv_mask as ONE convolution; output and every
+    parameter gradient must equal the reference formulation with two (reference :755-785)."""
     from modulated_deform_conv_amd import modulated_deform_conv as mdc
     torch.manual_seed(1)
     cls = mdc.ModulatedDeformConv2dPack if nd == 2 else mdc.ModulatedDeformConv3dPack
     base = mdc.ModulatedDeformConv2d if nd == 2 else mdc.ModulatedDeformConv3d
     m = cls(8, 6, 3, stride=1, padding=1, deformable_groups=2, bias=True).cuda()
-    m.own_side_conv = own
     assert set(k.split(".")[0] for k in m.state_dict()) == {"weight", "bias", "conv_offset", "conv_mask"}
     x = torch.randn(2, 8, *([7] * nd), device="cuda", requires_grad=True)
     y = m(x)
@@ -112,38 +108,9 @@ def test_pack_fused_side_conv_equals_two_convs(nd, own):
     y2 = base.forward(m, x, m.conv_offset(x), m.conv_mask(x))
     y2.square().sum().backward()
     want = [x.grad] + [p.grad for p in m.parameters()]
-    assert_close("output", y, y2, 1e-4)
+    assert_close("output", y, y2, 1e-5)
     for a, b in zip(got, want):
         assert_close("grad", a, b, 1e-4)
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-def test_pack_forward_launches_no_cat_or_copy_kernels(dtype):
-    """the default Pack forward concatenates the two side-convolution weights and copies
-    the two halves of the fused result (the FASTEST measured variant, see _side).  With own_side_conv the side
-    convolution is the library's own kernel with two contiguous results: no Cat / copy / framework-convolution
-    kernels in the forward."""
-    from torch.profiler import ProfilerActivity, profile
-    from modulated_deform_conv_amd import modulated_deform_conv as mdc
-    torch.manual_seed(3)
-    m = mdc.ModulatedDeformConv2dPack(64, 64, 3, padding=1, bias=True).cuda().to(dtype)
-    m.own_side_conv = True
-    x = torch.randn(2, 64, 20, 20, device="cuda", dtype=dtype)
-    with torch.no_grad():
-        m(x)
-        torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            y = m(x)
-            torch.cuda.synchronize()
-    names = [e.key for e in prof.key_averages()]
-    assert any("mfma_fwd" in n or "hp_fwd" in n for n in names), names
-    bad = [n for n in names if "Cat" in n or "copy" in n.lower() or "miopen" in n.lower() or "igemm" in n.lower()
-           or "conv" in n.lower() and "mdconv" not in n]
-    assert not bad, names
-    co, cm = m.conv_offset, m.conv_mask
-    want = mdc.ModulatedDeformConv2d.forward(m, x, co(x), cm(x))
-    # fp16: the two formulations round their offsets (about a pixel) to fp16 independently -- 1e-3 px apart
-    assert_close("pack", y.float(), want.float(), 1e-4 if dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -291,7 +258,6 @@ def test_pack_module_matches_oracle(cls_name, nd, modulated, kw):
     stride, groups, dg = kw.get("stride", 1), kw.get("groups", 1), kw.get("deformable_groups", 1)
     mod = getattr(mdc, cls_name)(C, O, 3, stride=stride, padding=1, groups=groups,
                                  deformable_groups=dg, bias=True).cuda()
-    mod.own_side_conv = nd == 3      # the 3-D packs through the library's own side-convolution kernel
     with torch.no_grad():
         mod.bias.normal_(0, 0.1)
         mod.conv_offset.bias.normal_(0, 0.3)       # the reference initialises these to 0; make them count

@@ -1,21 +1,20 @@
-python - <<PY
-import torch, sys
+mkdir -p gpurun_out
+rm -f gpurun_out/b21.txt
+for v in default fng fni fnm fnall; do
+L=""; [ $v != default ] && L=$PWD/modulated_deform_conv_amd/libmdconv_hip_$v.so
+echo "== $v" >> gpurun_out/b21.txt
+MDCONV_LIB=$L python - >> gpurun_out/b21.txt 2>&1 <<'PY'
+import sys, torch
 sys.path.insert(0, ".")
-from modulated_deform_conv_amd import modulated_deform_conv as mdc
-def t(fn, n=20):
-    fn(); torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(n): fn()
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / n
-for (C, B, S, dt) in ((256, 32, 56, torch.float32), (256, 32, 56, torch.float16), (64, 4, 28, torch.float32), (64, 4, 28, torch.float16), (128, 8, 40, torch.float32)):
-    m = mdc.ModulatedDeformConv2dPack(C, C, 3, padding=1, bias=True).cuda().to(dt)
-    x = torch.randn(B, C, S, S, device="cuda", dtype=dt)
-    co, cm = m.conv_offset, m.conv_mask
-    def fused():
-        y = torch.nn.functional.conv2d(x, torch.cat((co.weight, cm.weight)), torch.cat((co.bias, cm.bias)), 1, 1)
-        return y[:, :18].contiguous(), y[:, 18:].contiguous()
-    with torch.no_grad():
-        print(C, B, S, dt, "own %.3f  two-convs %.3f  fused-framework %.3f ms" % (t(lambda: m._side(x)), t(lambda: (co(x), cm(x))), t(fused)))
+import bench
+wl = bench.Workload("cfg5", "cuda")
+for _ in range(3): wl.forward()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): wl.forward()
+e1.record(); torch.cuda.synchronize()
+print("cfg5 fwd %.3f ms" % (e0.elapsed_time(e1) / 10))
 PY
+done
+cat gpurun_out/b21.txt
