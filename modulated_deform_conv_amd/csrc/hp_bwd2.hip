@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
       auto consume = [&](int k, int slot) {
         if (it_on[k]) {
           if (tile_ok)   // all pixels of the tile in one image: scalar base, dead pixels out of range (dropped)
-            buf_store4u(r_gcol, grow[slot] + it_oc[k] * 16, 0, gq[slot]);
+            buf_store4u_nt(r_gcol, grow[slot] + it_oc[k] * 16, 0, gq[slot]);
           else if (grow[slot] != kHpOob)
             *reinterpret_cast<U4 *>(gcol + (size_t)gimg[slot] * gcol_img + (grow[slot] >> 1) + it_oc[k] * 8) = gq[slot];
           float col[8], S[NC];
