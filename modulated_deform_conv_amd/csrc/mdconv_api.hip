@@ -153,8 +153,7 @@ int fill_geom(const mdconv_desc *d, Geom *g) {
 }
 
 // One line on stderr, once per process, when a shape with matrix-sized channel counts runs on the
-// shape-generic VALU kernels (an order of magnitude slower than the matrix-core kernels): the fp32 matrix
-// backward takes deformable groups of 64 / 128 / k * 256 channels only, and nothing else tells the user
+// shape-generic VALU kernels (an order of magnitude slower than the matrix-core kernels): nothing else tells the user
 // (mdconv_last_kernels() reports it per call; MDCONV_QUIET=1 silences the line).
 static void note_direct_fallback(const Geom &g, int dtype, bool backward) {
   static std::atomic<bool> said{false};
@@ -166,7 +165,7 @@ static void note_direct_fallback(const Geom &g, int dtype, bool backward) {
           "mdconv: %s of a %d-D shape with C_in=%d C_out=%d groups=%d deformable_groups=%d runs on the shape-generic "
           "kernels (the matrix-core kernels need %s); expect it to be ~10x slower. This note is printed once.\n",
           backward ? "backward" : "forward", g.nd, g.C, g.O, g.G, g.DG,
-          backward ? "C_in/deformable_groups in {64, 128, k*256} for fp32, a multiple of 32 for 16-bit tensors"
+          backward ? "C_in/deformable_groups a multiple of 8, at least 16, aligned with the conv groups"
                    : "C_in/deformable_groups a multiple of 32 (16 for 16-bit tensors)");
 }
 

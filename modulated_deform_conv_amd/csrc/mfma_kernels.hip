@@ -487,7 +487,7 @@ int direct16_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipS
   return MDCONV_OK;
 }
 
-bool mfma_supported(const Geom &g, int dtype, bool backward) {
+static bool native_supported(const Geom &g, int dtype, bool backward) {
   if (dtype != MDCONV_F32 && dtype != MDCONV_F16 && dtype != MDCONV_BF16) return false;
   if (g.in_sz[g.nd - 1] < 2) return false;   // paired-corner gathers need 2 columns
   if (!backward) {
@@ -504,7 +504,7 @@ bool mfma_supported(const Geom &g, int dtype, bool backward) {
   return make_plan(g, dtype, backward, &p);   // one image must fit 32-bit buffer offsets
 }
 
-size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
+static size_t native_workspace_bytes(const Geom &g, int dtype, bool backward) {
   Plan p;
   if (!make_plan(g, dtype, backward, &p)) return 0;
   return p.total;
@@ -563,7 +563,7 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
   return MDCONV_OK;
 }
 
-int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+static int native_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
   Plan p;
   if (!make_plan(g, dtype, true, &p)) { set_error("mfma_backward: no plan"); return MDCONV_EUNSUPPORTED; }
   char *base = (char *)ws;
@@ -620,6 +620,155 @@ int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStrea
     if ((rc = record_weight_ready(stream))) return rc;
   }
   return MDCONV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward for deformable groups the kernels above do not tile (C_in / DG of 16, 24, 32, 40 ...): the
+// gradients of deformable group dg involve its own input channels, offsets and masks and nothing of the
+// other groups (mdeformable_conv.cu:231 indexes the offsets by c / channel_per_deformable_group), so the
+// call is DG independent single-group problems over channel slices -- each copied into the workspace
+// (strided 2-D copies, a few % of the kernels' traffic), run through the same matrix-core pipeline and
+// copied back.  Slower per sample than a native tiling (C_in / DG = 32 fills half of a 64-channel tile)
+// but an order of magnitude faster than the shape-generic scatter kernels these shapes used to reach.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct SplitPlan {
+  Geom gs;            // one slice: DG = 1, C = C_in / DG, the conv groups / output channels it touches
+  bool copy_w, copy_go;
+  size_t off_x, off_off, off_m, off_go, off_w, off_gi, off_goff, off_gm, off_gw, off_sub, sub_bytes, total;
+};
+bool split_slice_geom(const Geom &g, Geom *out, bool *copy_w, bool *copy_go) {
+  if (g.DG <= 1 || g.Cdg < 16 || g.Cdg % 8) return false;
+  Geom s = g;
+  s.DG = 1; s.C = g.Cdg; s.Cdg = g.Cdg; s.with_bias = 0;
+  if (g.Cg % g.Cdg == 0) {          // the slice lies inside one conv group
+    s.G = 1; s.Cg = g.Cdg; s.O = s.Og = g.Og;
+    *copy_w = g.Cg != g.Cdg;
+  } else if (g.Cdg % g.Cg == 0) {   // the slice is a run of whole conv groups
+    s.G = g.Cdg / g.Cg; s.Cg = g.Cg; s.Og = g.Og; s.O = s.G * g.Og;
+    *copy_w = false;
+  } else {
+    return false;
+  }
+  *copy_go = s.O != g.O;
+  *out = s;
+  return true;
+}
+bool split_plan(const Geom &g, int dtype, SplitPlan *p) {
+  if (!split_slice_geom(g, &p->gs, &p->copy_w, &p->copy_go)) return false;
+  if (!native_supported(p->gs, dtype, true)) return false;
+  const size_t es = dtype == MDCONV_F32 ? 4 : 2;
+  const Geom &s = p->gs;
+  size_t off = 0;
+  auto take = [&](size_t &slot, size_t elems) { slot = off; off += align_up(elems * es); };
+  take(p->off_x, (size_t)g.B * s.C * g.S_i);
+  take(p->off_off, (size_t)g.B * g.nd * g.K * g.S_o);
+  take(p->off_m, g.modulated ? (size_t)g.B * g.K * g.S_o : 0);
+  take(p->off_go, p->copy_go ? (size_t)g.B * s.O * g.S_o : 0);
+  take(p->off_w, p->copy_w ? (size_t)s.O * s.Cg * g.K : 0);
+  take(p->off_gi, (size_t)g.B * s.C * g.S_i);
+  take(p->off_goff, (size_t)g.B * g.nd * g.K * g.S_o);
+  take(p->off_gm, g.modulated ? (size_t)g.B * g.K * g.S_o : 0);
+  take(p->off_gw, p->copy_w ? (size_t)s.O * s.Cg * g.K : 0);
+  p->off_sub = off;
+  p->sub_bytes = native_workspace_bytes(s, dtype, true);
+  p->total = off + p->sub_bytes;
+  return true;
+}
+int copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipStream_t stream) {
+  if (width == 0 || rows == 0) return MDCONV_OK;
+  hipError_t e = (dpitch == width && spitch == width)
+                     ? hipMemcpyAsync(dst, src, width * rows, hipMemcpyDeviceToDevice, stream)
+                     : hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) {
+    set_error("slice copy failed: %s", hipGetErrorString(e));
+    return MDCONV_ELAUNCH;
+  }
+  return MDCONV_OK;
+}
+
+int split_backward(const Geom &g, int dtype, const SplitPlan &p, const Tensors &t, void *ws, hipStream_t stream) {
+  char *base = (char *)ws;
+  const size_t es = dtype == MDCONV_F32 ? 4 : 2;
+  const Geom &s = p.gs;
+  const size_t w_x = (size_t)s.C * g.S_i * es, p_x = (size_t)g.C * g.S_i * es;
+  const size_t w_off = (size_t)g.nd * g.K * g.S_o * es, p_off = w_off * g.DG;
+  const size_t w_m = (size_t)g.K * g.S_o * es, p_m = w_m * g.DG;
+  const size_t w_go = (size_t)s.O * g.S_o * es, p_go = (size_t)g.O * g.S_o * es;
+  const size_t w_w = (size_t)s.Cg * g.K * es, p_w = (size_t)g.Cg * g.K * es;
+  int rc;
+  for (int dg = 0; dg < g.DG; ++dg) {
+    const int c0 = dg * g.Cdg;            // first input channel of the slice
+    const int grp = c0 / g.Cg;            // first conv group it touches
+    const int o0 = grp * g.Og;            // first output channel of those groups
+    const int cw = c0 - grp * g.Cg;       // channel offset inside the group's weight rows
+    Tensors ts = t;
+    const char *src_x = (const char *)t.input + (size_t)c0 * g.S_i * es;
+    const char *src_off = (const char *)t.offset + (size_t)dg * w_off;
+    char *dst_gi = (char *)t.grad_input + (size_t)c0 * g.S_i * es;
+    char *dst_goff = (char *)t.grad_offset + (size_t)dg * w_off;
+    char *dst_gw = (char *)t.grad_weight + ((size_t)o0 * g.Cg + cw) * g.K * es;
+    if ((rc = copy_rows(base + p.off_x, w_x, src_x, p_x, w_x, g.B, stream))) return rc;
+    if ((rc = copy_rows(base + p.off_off, w_off, src_off, p_off, w_off, g.B, stream))) return rc;
+    ts.input = base + p.off_x; ts.offset = base + p.off_off;
+    ts.grad_input = base + p.off_gi; ts.grad_offset = base + p.off_goff;
+    if (g.modulated) {
+      if ((rc = copy_rows(base + p.off_m, w_m, (const char *)t.mask + (size_t)dg * w_m, p_m, w_m, g.B, stream))) return rc;
+      ts.mask = base + p.off_m; ts.grad_mask = base + p.off_gm;
+    }
+    ts.grad_output = (const char *)t.grad_output + (size_t)o0 * g.S_o * es;
+    if (p.copy_go) {
+      if ((rc = copy_rows(base + p.off_go, w_go, ts.grad_output, p_go, w_go, g.B, stream))) return rc;
+      ts.grad_output = base + p.off_go;
+    }
+    ts.weight = (const char *)t.weight + ((size_t)o0 * g.Cg + cw) * g.K * es;
+    ts.grad_weight = dst_gw;
+    if (p.copy_w) {
+      if ((rc = copy_rows(base + p.off_w, w_w, ts.weight, p_w, w_w, s.O, stream))) return rc;
+      ts.weight = base + p.off_w; ts.grad_weight = base + p.off_gw;
+    }
+    Geom gs = s;
+    // grad_bias belongs to the output channels: once per conv group, with the first slice that touches it
+    gs.with_bias = g.with_bias && cw == 0 ? 1 : 0;
+    ts.bias = nullptr;
+    ts.grad_bias = gs.with_bias ? (char *)t.grad_bias + (size_t)o0 * es : nullptr;
+    if (g.acc_data) {   // accumulate mode: the slice starts from the caller's values
+      if ((rc = copy_rows(base + p.off_gi, w_x, dst_gi, p_x, w_x, g.B, stream))) return rc;
+      if ((rc = copy_rows(base + p.off_goff, w_off, dst_goff, p_off, w_off, g.B, stream))) return rc;
+      if (g.modulated &&
+          (rc = copy_rows(base + p.off_gm, w_m, (const char *)t.grad_mask + (size_t)dg * w_m, p_m, w_m, g.B, stream)))
+        return rc;
+    }
+    if (g.acc_w && p.copy_w && (rc = copy_rows(base + p.off_gw, w_w, dst_gw, p_w, w_w, s.O, stream))) return rc;
+    if ((rc = native_backward(gs, dtype, ts, base + p.off_sub, stream))) return rc;
+    if ((rc = copy_rows(dst_gi, p_x, base + p.off_gi, w_x, w_x, g.B, stream))) return rc;
+    if ((rc = copy_rows(dst_goff, p_off, base + p.off_goff, w_off, w_off, g.B, stream))) return rc;
+    if (g.modulated &&
+        (rc = copy_rows((char *)t.grad_mask + (size_t)dg * w_m, p_m, base + p.off_gm, w_m, w_m, g.B, stream)))
+      return rc;
+    if (p.copy_w && (rc = copy_rows(dst_gw, p_w, base + p.off_gw, w_w, w_w, s.O, stream))) return rc;
+  }
+  return record_weight_ready(stream);   // after the last slice's copies
+}
+}  // namespace
+
+bool mfma_supported(const Geom &g, int dtype, bool backward) {
+  if (native_supported(g, dtype, backward)) return true;
+  SplitPlan p;
+  return backward && split_plan(g, dtype, &p);
+}
+
+size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
+  if (native_supported(g, dtype, backward)) return native_workspace_bytes(g, dtype, backward);
+  SplitPlan p;
+  return backward && split_plan(g, dtype, &p) ? p.total : 0;
+}
+
+int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  if (native_supported(g, dtype, true)) return native_backward(g, dtype, t, ws, stream);
+  SplitPlan p;
+  if (!split_plan(g, dtype, &p)) { set_error("mfma_backward: no plan"); return MDCONV_EUNSUPPORTED; }
+  return split_backward(g, dtype, p, t, ws, stream);
 }
 
 }  // namespace mdconv

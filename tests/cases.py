@@ -49,6 +49,14 @@ CASES = [
     _c("mfma_mdcn3d_g2_dg2_c128_o32", M3, 1, 128, 32, (5, 6, 5), 3, groups=2, dgroups=2, in_step=1, tier="medium", seed=34),
     _c("cfg3s_mdcn2d_c256_g32_dg4_10x10", M2, 2, 256, 256, (10, 10), 3, groups=32, dgroups=4, bias=False, tier="medium", seed=35),
     _c("mfma_dcn2d_dg4_c1024_o16", D2, 1, 1024, 16, (6, 6), 3, dgroups=4, bias=False, tier="medium", seed=36),
+    # deformable groups the fp32 matrix-core backward does not tile (C_in/DG of 16, 24, 32, 48): DG independent
+    # single-group slices (mfma_kernels.hip, split_backward) -- one conv group, a slice inside a conv group
+    # (weight / grad_output slices), a slice made of whole conv groups, 3-D
+    _c("mfma_split_mdcn2d_dg4_c128_o128", M2, 2, 128, 128, (14, 13), 3, dgroups=4, tier="medium", seed=71),
+    _c("mfma_split_dcn2d_g2_dg4_c128_o64", D2, 3, 128, 64, (9, 11), 3, groups=2, dgroups=4, in_step=1, tier="medium", seed=72),
+    _c("mfma_split_mdcn2d_g4_dg2_c96_o64", M2, 2, 96, 64, (10, 9), 3, groups=4, dgroups=2, bias=False, tier="medium", seed=73),
+    _c("mfma_split_mdcn3d_dg2_c32_o32", M3, 2, 32, 32, (5, 6, 5), 3, dgroups=2, in_step=1, tier="medium", seed=74),
+    _c("mfma_split_dcn3d_s2_dg2_c48_o24", D3, 1, 48, 24, (7, 6, 7), 3, stride=2, dgroups=2, tier="medium", seed=75),
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),

@@ -24,7 +24,7 @@ def _random_case(seed):
     dg_choice = r.choice([1, 1, 2])
     # channels: multiples of 8 (MFMA backward), >= 16, divisible by groups and deformable groups
     if dg_choice > 1:
-        cdg = r.choice([64, 128])
+        cdg = r.choice([16, 32, 64, 128])
         C = cdg * dg_choice
         while C % groups:
             groups //= 2

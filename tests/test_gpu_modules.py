@@ -209,6 +209,7 @@ def test_weight_ready_event_orders_a_side_stream():
 @pytest.mark.parametrize("name, dtype", [
     ("cfg2s_mdcn2d_c64_28x28_b4", torch.float32), ("cfg4s_dcn3d_c16_12cubed_b2", torch.float32),
     ("mfma_mdcn2d_g4_dg2_c128_o64", torch.float32),
+    ("mfma_split_dcn2d_g2_dg4_c128_o64", torch.float32),   # per-deformable-group slices: strided copy nodes
     ("cfg5s_mdcn3d_c16_dil2", torch.float16),       # hp_bwd3 + hp_gemm2 + two-pass gather, tails forked
     ("mfma_mdcn2d_g4_dg2_c128_o64", torch.float16)])   # hp_bwd2 (fused)
 def test_hip_graph_capture_and_replay(name, dtype):
