@@ -158,6 +158,7 @@ int fill_geom(const mdconv_desc *d, Geom *g) {
 static void note_direct_fallback(const Geom &g, int dtype, bool backward) {
   static std::atomic<bool> said{false};
   if (g.Cg < 16 || g.Og < 16 || dtype == MDCONV_F64 || current_path() == MDCONV_PATH_DIRECT) return;
+  if (!backward && g.Cg < 64) return;   // narrow conv groups: the shape-generic forward is no slower (mfma_kernels.hip)
   if (said.exchange(true)) return;
   const char *q = getenv("MDCONV_QUIET");
   if (q && atoi(q) != 0) return;
@@ -166,7 +167,7 @@ static void note_direct_fallback(const Geom &g, int dtype, bool backward) {
           "kernels (the matrix-core kernels need %s); expect it to be ~10x slower. This note is printed once.\n",
           backward ? "backward" : "forward", g.nd, g.C, g.O, g.G, g.DG,
           backward ? "C_in/deformable_groups a multiple of 8, at least 16, aligned with the conv groups"
-                   : "C_in/deformable_groups a multiple of 32 (16 for 16-bit tensors)");
+                   : "C_in/deformable_groups a multiple of 8, at least 16, aligned with the conv groups");
 }
 
 static int require(const void *p, const char *name) {

@@ -510,7 +510,7 @@ static size_t native_workspace_bytes(const Geom &g, int dtype, bool backward) {
   return p.total;
 }
 
-int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+static int native_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
   Plan p;
   if (!make_plan(g, dtype, false, &p)) { set_error("mfma_forward: no plan"); return MDCONV_EUNSUPPORTED; }
   char *base = (char *)ws;
@@ -752,16 +752,108 @@ int split_backward(const Geom &g, int dtype, const SplitPlan &p, const Tensors &
 }
 }  // namespace
 
+// Forward of the same shapes: the slices of one conv group add up in its output channels, so each slice's
+// output goes to a workspace tile and is copied (first slice of the conv group: it carries the bias) or added
+// (fp32 only: adding rounded 16-bit outputs would round DG times) into the caller's rows.
+namespace {
+__global__ __launch_bounds__(256) void add_rows_kernel(float *__restrict__ dst, int64_t dpitch,
+                                                       const float *__restrict__ src, int64_t width, int64_t rows) {
+  const int64_t n = width * rows;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / width;
+    dst[r * dpitch + (i - r * width)] += src[i];
+  }
+}
+struct SplitFwdPlan {
+  Geom gs;
+  bool copy_w, copy_out;
+  size_t off_x, off_off, off_m, off_w, off_out, off_sub, total;
+};
+bool split_fwd_plan(const Geom &g, int dtype, SplitFwdPlan *p) {
+  if (!split_slice_geom(g, &p->gs, &p->copy_w, &p->copy_out)) return false;
+  if (g.Cg > g.Cdg && dtype != MDCONV_F32) return false;   // slices of one conv group are summed: fp32 only
+  // narrow conv groups are cheap on the shape-generic forward (C=128, 8 groups of 16, DG=4, 64x64, B=16: 0.3 ms
+  // faster there than as four slices with mostly-padding tiles); wide ones are not (one group, DG=8: 0.25 ms slower)
+  if (g.Cg < 64) return false;
+  if (!native_supported(p->gs, dtype, false)) return false;
+  const size_t es = dtype == MDCONV_F32 ? 4 : 2;
+  const Geom &s = p->gs;
+  size_t off = 0;
+  auto take = [&](size_t &slot, size_t elems) { slot = off; off += align_up(elems * es); };
+  take(p->off_x, (size_t)g.B * s.C * g.S_i);
+  take(p->off_off, (size_t)g.B * g.nd * g.K * g.S_o);
+  take(p->off_m, g.modulated ? (size_t)g.B * g.K * g.S_o : 0);
+  take(p->off_w, p->copy_w ? (size_t)s.O * s.Cg * g.K : 0);
+  take(p->off_out, (size_t)g.B * s.O * g.S_o);
+  p->off_sub = off;
+  p->total = off + native_workspace_bytes(s, dtype, false);
+  return true;
+}
+int split_forward(const Geom &g, int dtype, const SplitFwdPlan &p, const Tensors &t, void *ws, hipStream_t stream) {
+  char *base = (char *)ws;
+  const size_t es = dtype == MDCONV_F32 ? 4 : 2;
+  const Geom &s = p.gs;
+  const size_t w_x = (size_t)s.C * g.S_i * es, p_x = (size_t)g.C * g.S_i * es;
+  const size_t w_off = (size_t)g.nd * g.K * g.S_o * es, p_off = w_off * g.DG;
+  const size_t w_m = (size_t)g.K * g.S_o * es, p_m = w_m * g.DG;
+  const size_t w_out = (size_t)s.O * g.S_o * es, p_out = (size_t)g.O * g.S_o * es;
+  const size_t w_w = (size_t)s.Cg * g.K * es, p_w = (size_t)g.Cg * g.K * es;
+  int rc;
+  for (int dg = 0; dg < g.DG; ++dg) {
+    const int c0 = dg * g.Cdg, grp = c0 / g.Cg, o0 = grp * g.Og, cw = c0 - grp * g.Cg;
+    Tensors ts = t;
+    if ((rc = copy_rows(base + p.off_x, w_x, (const char *)t.input + (size_t)c0 * g.S_i * es, p_x, w_x, g.B, stream))) return rc;
+    if ((rc = copy_rows(base + p.off_off, w_off, (const char *)t.offset + (size_t)dg * w_off, p_off, w_off, g.B, stream))) return rc;
+    ts.input = base + p.off_x; ts.offset = base + p.off_off;
+    if (g.modulated) {
+      if ((rc = copy_rows(base + p.off_m, w_m, (const char *)t.mask + (size_t)dg * w_m, p_m, w_m, g.B, stream))) return rc;
+      ts.mask = base + p.off_m;
+    }
+    ts.weight = (const char *)t.weight + ((size_t)o0 * g.Cg + cw) * g.K * es;
+    if (p.copy_w) {
+      if ((rc = copy_rows(base + p.off_w, w_w, ts.weight, p_w, w_w, s.O, stream))) return rc;
+      ts.weight = base + p.off_w;
+    }
+    Geom gs = s;
+    gs.with_bias = g.with_bias && cw == 0 ? 1 : 0;
+    ts.bias = gs.with_bias ? (const char *)t.bias + (size_t)o0 * es : nullptr;
+    ts.output = base + p.off_out;
+    if ((rc = native_forward(gs, dtype, ts, base + p.off_sub, stream))) return rc;
+    char *dst = (char *)t.output + (size_t)o0 * g.S_o * es;
+    if (cw == 0) {
+      if ((rc = copy_rows(dst, p_out, base + p.off_out, w_out, w_out, g.B, stream))) return rc;
+    } else {
+      const int64_t width = (int64_t)s.O * g.S_o, n = width * g.B;
+      const int64_t blocks = (n + 255) / 256;
+      hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, stream,
+                         (float *)dst, (int64_t)g.O * g.S_o, (const float *)(base + p.off_out), width, (int64_t)g.B);
+      if ((rc = check_launch("add_rows"))) return rc;
+    }
+  }
+  return MDCONV_OK;
+}
+}  // namespace
+
 bool mfma_supported(const Geom &g, int dtype, bool backward) {
   if (native_supported(g, dtype, backward)) return true;
   SplitPlan p;
-  return backward && split_plan(g, dtype, &p);
+  SplitFwdPlan pf;
+  return backward ? split_plan(g, dtype, &p) : split_fwd_plan(g, dtype, &pf);
 }
 
 size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
   if (native_supported(g, dtype, backward)) return native_workspace_bytes(g, dtype, backward);
   SplitPlan p;
-  return backward && split_plan(g, dtype, &p) ? p.total : 0;
+  SplitFwdPlan pf;
+  if (backward) return split_plan(g, dtype, &p) ? p.total : 0;
+  return split_fwd_plan(g, dtype, &pf) ? pf.total : 0;
+}
+
+int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  if (native_supported(g, dtype, false)) return native_forward(g, dtype, t, ws, stream);
+  SplitFwdPlan p;
+  if (!split_fwd_plan(g, dtype, &p)) { set_error("mfma_forward: no plan"); return MDCONV_EUNSUPPORTED; }
+  return split_forward(g, dtype, p, t, ws, stream);
 }
 
 int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {

@@ -57,6 +57,8 @@ CASES = [
     _c("mfma_split_mdcn2d_g4_dg2_c96_o64", M2, 2, 96, 64, (10, 9), 3, groups=4, dgroups=2, bias=False, tier="medium", seed=73),
     _c("mfma_split_mdcn3d_dg2_c32_o32", M3, 2, 32, 32, (5, 6, 5), 3, dgroups=2, in_step=1, tier="medium", seed=74),
     _c("mfma_split_dcn3d_s2_dg2_c48_o24", D3, 1, 48, 24, (7, 6, 7), 3, stride=2, dgroups=2, tier="medium", seed=75),
+    _c("mfma_split_mdcn2d_dg8_c128_o32", M2, 2, 128, 32, (9, 10), 3, dgroups=8, tier="medium", seed=76),
+    _c("mfma_split_dcn3d_g2_dg8_c128_o32", D3, 1, 128, 32, (5, 5, 6), 3, groups=2, dgroups=8, in_step=1, tier="medium", seed=77),
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),

@@ -51,6 +51,14 @@ def test_backward_runs_on_the_mfma_path(case):
     assert _check(case, torch.float32, "auto")[1] == "mfma"
 
 
+@pytest.mark.parametrize("name", ["mfma_split_mdcn2d_dg8_c128_o32", "mfma_split_dcn3d_g2_dg8_c128_o32"])
+def test_forward_of_small_deformable_groups_runs_on_the_mfma_path(name):
+    """C_in/DG = 16 inside conv groups of 128 / 64 channels: per-slice forwards on the matrix-core kernels,
+    summed into the conv group's output channels (the first slice carries the bias)."""
+    from tests.cases import CASE_BY_NAME
+    assert _check(CASE_BY_NAME[name], torch.float32, "auto")[0] == "mfma"
+
+
 def test_fp16_grouped_mfma_backward():
     from tests.cases import CASE_BY_NAME
     assert _check(CASE_BY_NAME["cfg3s_mdcn2d_c256_g32_dg4_10x10"], torch.float16, "auto")[1] == "mfma"
