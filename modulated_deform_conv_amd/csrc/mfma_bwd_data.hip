@@ -104,6 +104,14 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
 // CL: the drain gathers from the channels-last input copy xt[b][q][c] (mfma_fwd_cl.hip): a lane
 // fetches 4 consecutive channels of ONE corner of its pixel with a 16-byte load -- half the load
 // instructions of the paired NCHW loads and, in 3-D, a third of the cache lines.
+#ifdef B1_TIMING
+// developer instrumentation (tools/b1_timing.py): cycles per phase of the main loop, summed over all waves
+__device__ unsigned long long g_b1_timing[12];
+#define B1_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define B1_T(slot) do { } while (0)
+#endif
+
 template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL>
 __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
@@ -213,6 +221,9 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
 
   // ---- the pixel this lane owns in the accumulator layout: of the tile whose K loop runs
   // (`c`) and of the tile whose accumulators are parked (`p`) ----
+#ifdef B1_TIMING
+  unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#endif
   struct Pix { int n0, b, pix; bool live; int oc[ND]; };
   auto pix_of_tile = [&](int tile, Pix &px) {
     px.n0 = tile * BNP;
@@ -241,6 +252,44 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     for (int o = osub; o < Opad; o += OSTEP) {
       const float v = src[(int64_t)min(o, g.O - 1) * g.S_o];
       dst[o] = (t_live && o < g.O) ? v : 0.f;
+    }
+  };
+
+  // The same tile as eight 16-byte loads per thread (4 consecutive pixels of one output channel each), all in
+  // flight at once -- the accumulator registers are free at a tile switch.  The scalar version above goes through
+  // four dependent rounds of 4-byte loads behind the draining grad_col stores, exposed between two barriers:
+  // 17 % of the kernel's wave-cycles at cfg2 (tools/b1_timing.py).
+  constexpr int PGS = BNP / 4;             // pixel quads per tile
+  constexpr int OPR = 256 / PGS;           // output channels covered by one round of the 256 threads
+  constexpr int kPre = 8;                  // rounds in flight together (a 32 KB tile); further rounds follow
+  const bool gout_vec = (g.S_o & 3) == 0 && (reinterpret_cast<uintptr_t>(gout) & 15) == 0;
+  auto load_gout_tile_vec = [&](int tile) {
+    const int Opad = T_o * 16;
+    const int rounds = (Opad + OPR - 1) / OPR;
+    const int j4 = (tid % PGS) * 4;
+    const bool live4 = tile * BNP + j4 < g.N;   // N is a multiple of 4 here: a quad is live or dead as a whole
+    const int n4 = min(tile * BNP + j4, g.N - 4);
+    const int b4 = n4 / g.S_o, pix4 = n4 - b4 * g.S_o;
+    const float *src = gout + ((int64_t)b4 * g.O) * g.S_o + pix4;
+    const int o0 = tid / PGS;
+    float *dst = Gs + j4 * gpitch + o0;
+    for (int r0 = 0; r0 < rounds; r0 += kPre) {
+      float4 v[kPre];
+#pragma unroll
+      for (int i = 0; i < kPre; ++i)   // clamped address: always a valid 16-byte load
+        v[i] = *reinterpret_cast<const float4 *>(src + (int64_t)min((r0 + i) * OPR + o0, g.O - 1) * g.S_o);
+#pragma unroll
+      for (int i = 0; i < kPre; ++i) {
+        const int o = (r0 + i) * OPR + o0;
+        if (o < Opad) {
+          const bool on = live4 && o < g.O;
+          float *d = dst + (r0 + i) * OPR;
+          d[0] = on ? v[i].x : 0.f;
+          d[gpitch] = on ? v[i].y : 0.f;
+          d[2 * gpitch] = on ? v[i].z : 0.f;
+          d[3 * gpitch] = on ? v[i].w : 0.f;
+        }
+      }
     }
   };
 
@@ -655,14 +704,21 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       if (per_block) new_tap_state(tapp, min(blk * 64, g.C - 1) / g.Cdg, blk % bpd == 0 && blk * 64 < g.C);
       else new_tap_state(tapp, 0, wc == 0);
     }
+    B1_T(0);   // tap state of the parked tap
     if (tile != tile_c) {
       if (tile_c >= 0) __syncthreads();   // every wave is done with the previous tile's K loops
-      load_gout_tile(tile);
+      B1_T(8);   // barrier: previous tile done
+      if (gout_vec) load_gout_tile_vec(tile);
+      else load_gout_tile(tile);
       pix_of_tile(tile, pc);
       tile_c = tile;
+      B1_T(9);   // grad_out tile: global loads -> LDS
       __syncthreads();
+      B1_T(10);  // barrier: tile complete
       if (tap == 0 && pass == 0) emit_ga(tile);
+      B1_T(11);  // ga emission, grad_bias partials
     }
+    B1_T(1);
     if (pass == 0 || per_block) {
       const int dg = per_block ? min((pass * WAVES_C + wc) * 64, g.C - 1) / g.Cdg : 0;
       const int64_t seg = (int64_t)pc.b * g.DG + dg;
@@ -697,10 +753,12 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       Batch v;
       // straight-line path: the A fragment of chunk t+3 is requested BEFORE the gathers, so only
       // the fragment of chunk t+4 (needed four chunks later) queues behind them
+      B1_T(2);   // offsets / stream bookkeeping (first batch), loop overhead
       if (QPQ > 0) quad_head(q * QPQ * 4);
       gather(q, cbase_p, v);
       asm volatile("" ::: "memory");   // IR-level fence: keep batch q's gathers here
       __builtin_amdgcn_sched_barrier(0);
+      B1_T(3);   // gather issue
       if (QPQ > 0) {
         quad_tail(q * QPQ * 4, q == 0);
 #pragma unroll
@@ -709,9 +767,11 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
         for (int qd = nq * q / NBATCH; qd < nq * (q + 1) / NBATCH; ++qd) quad(qd * 4, false);
       }
       __builtin_amdgcn_sched_barrier(0);
+      B1_T(4);   // MFMA quads (A fragment loads, LDS B reads)
       consume(q, cbase_p, v);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      B1_T(5);   // consume: wait for the gathers, corner sums, grad_col rows
     }
     // the parked tap is complete after its last pass (per block: after every pass); its group is
     // flushed at a group / tile end
@@ -719,6 +779,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     if (it > 0 && (passp == passes - 1 || per_block))
       finish_tap(tapp, per_block ? passp * WAVES_C + wc : wc, passp == passes - 1, false);
     park();
+    B1_T(6);   // collect / finish_tap / park
     pp = pc;
     tapp = tap;
     passp = pass;
@@ -735,20 +796,45 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       else new_tap_state(tapp, 0, wc == 0);
     }
     const int cbase_p = (passp * WAVES_C + wc) * 64;
+    // no K loop left to hide the gathers behind: two batches in flight at a time (the accumulator and
+    // A-fragment registers are free now), half as many exposed round trips.  With one tile per workgroup this
+    // block is 1 of 10 drains: it measured 9.7 % of the kernel's wave-cycles at cfg2 one batch at a time.
+    static_assert(NBATCH % 2 == 0, "pairs of drain batches");
 #pragma unroll
-    for (int q = 0; q < NBATCH; ++q) {
-      Batch v;
-      gather(q, cbase_p, v);
+    for (int q = 0; q < NBATCH; q += 2) {
+      Batch v0, v1;
+      gather(q, cbase_p, v0);
+      gather(q + 1, cbase_p, v1);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      consume(q, cbase_p, v);
+      consume(q, cbase_p, v0);
+      consume(q + 1, cbase_p, v1);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
     collect();
     finish_tap(tapp, per_block ? passp * WAVES_C + wc : wc, true, true);
   }
+#ifdef B1_TIMING
+  B1_T(7);   // drain of the last iteration
+  if (lane == 0)
+    for (int i = 0; i < 12; ++i) atomicAdd(&g_b1_timing[i], t_acc[i]);
+#endif
 }
+
+#ifdef B1_TIMING
+}  // namespace
+}  // namespace mdconv
+extern "C" void mdconv_debug_timing_b1(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdconv::g_b1_timing), sizeof(mdconv::g_b1_timing));
+  if (reset) {
+    unsigned long long z[12] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mdconv::g_b1_timing), z, sizeof(z));
+  }
+}
+namespace mdconv {
+namespace {
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // 2. inverse scatter map (CSR keyed by (image, deformable group, input pixel))

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Developer aid: per-phase cycle breakdown of mfma_bwd_data_kernel (GEMM-1 of the fp32 backward).  Needs the
+B1_TIMING build variant:
+  python -c "from modulated_deform_conv_amd import _build; print(_build.build_one_file_variant('b1t', 'mfma_bwd_data.hip', ['-DB1_TIMING']))"
+  MDCONV_LIB=.../libmdconv_hip_b1t.so python tools/b1_timing.py cfg2 cfg4"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from modulated_deform_conv_amd import _capi
+import bench
+L = _capi.lib()
+buf = (ctypes.c_ulonglong * 12)()
+labels = ["tap state", "-", "bookkeeping", "gather issue", "MFMA quads", "consume", "collect/finish/park",
+          "last drain", "barrier (previous tile done)", "grad_out tile -> LDS", "barrier (tile complete)", "ga emission + grad_bias"]
+for name in (sys.argv[1:] or ["cfg2"]):
+    wl = bench.Workload(name, "cuda")
+    wl.backward(); torch.cuda.synchronize()
+    L.mdconv_debug_timing_b1(buf, 1)
+    wl.backward(); torch.cuda.synchronize()
+    L.mdconv_debug_timing_b1(buf, 1)
+    tot = float(sum(buf))
+    print(name + ": " + "  ".join("%s %.1f%%" % (labels[i], 100.0 * buf[i] / max(tot, 1.0)) for i in range(12)),
+          " (total %.3g wave-cycles)" % tot)
