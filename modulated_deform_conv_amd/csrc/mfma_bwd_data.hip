@@ -74,13 +74,15 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
 // 1. GEMM-1 + coordinate gradients + grad_col stream
 // ---------------------------------------------------------------------------------------------
 // Work decomposition: a UNIT is one (pixel tile, tap); a workgroup walks a contiguous unit range.
-// The first n_full workgroups (a whole number of dispatch rounds, 2 workgroups per CU) take one
-// tile = K units each; the units of the leftover tiles are spread evenly over one last round of
+// The first n_full workgroups (a whole number of dispatch rounds, 2 workgroups per CU) take two
+// tiles = 2 K units each; the units of the leftover tiles are spread evenly over one last round of
 // short workgroups.  (With one workgroup per tile, cfg2's 3136 tiles over 512 slots left the
 // seventh round 1/8 full: ~12 % of the kernel.  A fully persistent grid -- one long unit range
 // per slot -- was measured 25 % SLOWER: every workgroup then runs in phase with every other and
 // they all hit the same few L2 channels at the same time; 2 / 3 / 6 tiles per workgroup: 1.28 /
-// 1.31 / 1.40 ms vs 1.26 for one; 5 / 3 / 1 taps per workgroup: 1.44 / 1.46 / 2.06 ms.)  A tile
+// 1.31 / 1.40 ms vs 1.26 for one; 5 / 3 / 1 taps per workgroup: 1.44 / 1.46 / 2.06 ms.  Round 3, with the
+// tile load no longer exposed: 1 / 2 / 3 / 6 tiles per workgroup of the full rounds = 1.092 / 1.074 / 1.077 /
+// 1.072 ms -- two it is, MDCONV_BD_TPW overrides.)  A tile
 // split between workgroups
 // needs no atomics: grad_col, grad_offset and grad_mask are all per-tap outputs.
 //
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
     float *__restrict__ ga, float *__restrict__ bias_part, int *__restrict__ cnt,
-    int *__restrict__ table, const float *__restrict__ xt, int ntiles, int n_full, int n_tail) {
+    int *__restrict__ table, const float *__restrict__ xt, int ntiles, int n_full, int n_tail, int tpw) {
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -145,13 +147,13 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   // Neighbouring ranges share an XCD, hence an L2.
   int u0, u1;
   if ((int)blockIdx.x < n_full) {
-    u0 = xcd_remap(blockIdx.x, n_full) * g.K;
-    u1 = u0 + g.K;
+    u0 = xcd_remap(blockIdx.x, n_full) * g.K * tpw;
+    u1 = u0 + g.K * tpw;
   } else {
     const int j = xcd_remap(blockIdx.x - n_full, n_tail);
-    const int64_t tail_units = (int64_t)(ntiles - n_full) * g.K;
-    u0 = n_full * g.K + (int)(tail_units * j / n_tail);
-    u1 = n_full * g.K + (int)(tail_units * (j + 1) / n_tail);
+    const int64_t tail_units = (int64_t)(ntiles - n_full * tpw) * g.K;
+    u0 = n_full * tpw * g.K + (int)(tail_units * j / n_tail);
+    u1 = n_full * tpw * g.K + (int)(tail_units * (j + 1) / n_tail);
   }
   if (u0 >= u1) return;
 
@@ -1231,14 +1233,16 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
     /* then the units of the leftover tiles spread over one more, shorter, round              */ \
     const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;                                           \
     const int slots = num_cus() * per_cu;                                                       \
-    const int n_full = ntiles / slots * slots;                                                  \
-    const int n_tail = (int)std::min<int64_t>((int64_t)(ntiles - n_full) * g.K, slots);         \
+    static const int tpw_env = getenv("MDCONV_BD_TPW") ? atoi(getenv("MDCONV_BD_TPW")) : 2;     \
+    const int tpw = tpw_env > 0 ? tpw_env : 1;   /* whole tiles per workgroup of the full rounds */ \
+    const int n_full = ntiles / (slots * tpw) * slots;                                          \
+    const int n_tail = (int)std::min<int64_t>((int64_t)(ntiles - n_full * tpw) * g.K, slots);   \
     hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>), dim3(n_full + n_tail),    \
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
                        (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, table, xt,        \
-                       ntiles, n_full, n_tail);                                                 \
+                       ntiles, n_full, n_tail, tpw);                                            \
   } while (0)
 /* channels-last drain only where it pays (3-D) */                                                \
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
