@@ -12,12 +12,17 @@ L = _capi.lib()
 buf = (ctypes.c_ulonglong * 12)()
 labels = ["tap state", "-", "bookkeeping", "gather issue", "MFMA quads", "consume", "collect/finish/park",
           "last drain", "barrier (previous tile done)", "grad_out tile -> LDS", "barrier (tile complete)", "ga emission + grad_bias"]
-for name in (sys.argv[1:] or ["cfg2"]):
+gemm2 = "--gemm2" in sys.argv   # needs the B2_TIMING variant of mfma_bwd_weight_cl.hip instead
+if gemm2:
+    buf = (ctypes.c_ulonglong * 8)()
+    labels = ["prologue", "commit", "barrier", "tab issue", "MFMAs", "A issue", "gather issue (waits for its tab entry)", "partial stores"]
+read = L.mdconv_debug_timing_b2 if gemm2 else L.mdconv_debug_timing_b1
+for name in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg2"]):
     wl = bench.Workload(name, "cuda")
     wl.backward(); torch.cuda.synchronize()
-    L.mdconv_debug_timing_b1(buf, 1)
+    read(buf, 1)
     wl.backward(); torch.cuda.synchronize()
-    L.mdconv_debug_timing_b1(buf, 1)
+    read(buf, 1)
     tot = float(sum(buf))
-    print(name + ": " + "  ".join("%s %.1f%%" % (labels[i], 100.0 * buf[i] / max(tot, 1.0)) for i in range(12)),
+    print(name + ": " + "  ".join("%s %.1f%%" % (labels[i], 100.0 * buf[i] / max(tot, 1.0)) for i in range(len(labels))),
           " (total %.3g wave-cycles)" % tot)
