@@ -133,15 +133,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 || NKS >= 16 || ND == 3) ? 
   };
 
   // offsets / mask of the lane's pixel, one tile ahead
-  float dl[ND], ml = 1.f;
+  Raw dlr[ND], mlr;   // raw 16-bit values until they are needed (a conversion here is a use of the load where it is issued)
   auto fetch = [&](int tile) {
     const int nn = min(tile * 32 + pl, g.N - 1);
     const int bb = nn / g.S_o, pp = nn - bb * g.S_o;
     const int64_t seg = (int64_t)bb * g.DG + dg;
     const int64_t ob = (seg * (ND * g.K) + ND * tap) * g.S_o + pp;
 #pragma unroll
-    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(offset + ob + (int64_t)a * g.S_o);
-    if (MOD) ml = T::ldf(mask + (seg * g.K + tap) * g.S_o + pp);
+    for (int a = 0; a < ND; ++a) dlr[a] = offset[ob + (int64_t)a * g.S_o];
+    if (MOD) mlr = mask[(seg * g.K + tap) * g.S_o + pp];
   };
   if (t_lo < t_hi) fetch(t_lo);
 
@@ -161,8 +161,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 || NKS >= 16 || ND == 3) ? 
     int oc[ND];
     out_coords<ND>(g, pix, oc);
     TapCoef<ND, float> tc;
+    float dl[ND];
+#pragma unroll
+    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(&dlr[a]);
     make_tap<ND, float>(g, oc, tcd, dl, true, tc);
-    const float m_n = ml;
+    const float m_n = MOD ? T::ldf(&mlr) : 1.f;
     if (tile + 1 < t_hi) fetch(tile + 1);
     HpCorners<ND> hc;
     hp_corners<ND>(tc, hc);

@@ -118,11 +118,10 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
       out_coords<ND>(g, p_first, noc[ps]);
       advance_pixel<ND>(g, pl, nb[ps], noc[ps]);
     }
-    float dl[SP][ND], ml[SP];
+    Raw dlr[SP][ND], mlr[SP];   // raw 16-bit values until build() (a conversion in fetch() is a use of the load where it is issued)
     auto fetch = [&]() {   // offsets / mask of the pixel at (nb, noc)
 #pragma unroll
       for (int ps = 0; ps < SP; ++ps) {
-        ml[ps] = 1.f;
         if (on[ps]) {
           const int bb = min(nb[ps], g.B - 1);
           int pix = noc[ps][0];
@@ -131,8 +130,8 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
           const int64_t seg = (int64_t)bb * g.DG + dgi[ps];
           const int64_t ob = (seg * (ND * g.K) + ND * tap) * g.S_o + pix;
 #pragma unroll
-          for (int a = 0; a < ND; ++a) dl[ps][a] = T::ldf(offset + ob + (int64_t)a * g.S_o);
-          if (MOD) ml[ps] = T::ldf(mask + (seg * g.K + tap) * g.S_o + pix);
+          for (int a = 0; a < ND; ++a) dlr[ps][a] = offset[ob + (int64_t)a * g.S_o];
+          if (MOD) mlr[ps] = mask[(seg * g.K + tap) * g.S_o + pix];
         }
       }
     };
@@ -150,18 +149,22 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
           int pix = noc[ps][0];
 #pragma unroll
           for (int a = 1; a < ND; ++a) pix = pix * g.out_sz[a] + noc[ps][a];
+          float dlf[ND], mlf = 1.f;
+#pragma unroll
+          for (int a = 0; a < ND; ++a) dlf[a] = T::ldf(&dlr[ps][a]);
+          if (MOD) mlf = T::ldf(&mlr[ps]);
           TapCoef<ND, float> tc;
-          make_tap<ND, float>(g, noc[ps], tcd, dl[ps], true, tc);
+          make_tap<ND, float>(g, noc[ps], tcd, dlf, true, tc);
           HpCorners<ND> hc;
           hp_corners<ND>(tc, hc);
-          f.mg = (!g.range_gate || tc.inside) ? ml[ps] : 0.f;
+          f.mg = (!g.range_gate || tc.inside) ? mlf : 0.f;
 #pragma unroll
           for (int a = 0; a < ND; ++a) { f.wl[a] = tc.wl[a]; f.wh[a] = tc.wh[a]; f.sl[a] = tc.sl[a]; f.sh[a] = tc.sh[a]; }
           int ev[SW];
 #pragma unroll
           for (int ci = 0; ci < NC; ++ci) {
             ev[ci] = (f.live && hc.idx[ci] >= 0) ? (bb * g.S_i + hc.idx[ci]) * Cp * 2 : kHpOob;
-            ev[NC + ci] = __float_as_int(f.live ? hc.w[ci] * ml[ps] : 0.f);
+            ev[NC + ci] = __float_as_int(f.live ? hc.w[ci] * mlf : 0.f);
           }
           // grad_col row: byte offset inside its image's rows (one image's rows stay below the chunk
           // limit, a whole chunk's need not), and the image

@@ -128,16 +128,21 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
   }
 
   // ---- state role: offsets / mask one tap ahead ----
-  float dl[ND], ml = 1.f;
+  // (raw 16-bit values until build(): a conversion inside fetch() would be a use of the load where it is issued, hp_fwd2.hip)
+  Raw dlr[ND], mlr;
   const Raw *off_px = offset + (int64_t)b * (ND * g.K) * g.S_o + pix;
   const Raw *msk_px = MOD ? mask + (int64_t)b * g.K * g.S_o + pix : nullptr;
   auto fetch = [&](int tap) {
 #pragma unroll
-    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(off_px + ((int64_t)tap * ND + a) * g.S_o);
-    if (MOD) ml = T::ldf(msk_px + (int64_t)tap * g.S_o);
+    for (int a = 0; a < ND; ++a) dlr[a] = off_px[((int64_t)tap * ND + a) * g.S_o];
+    if (MOD) mlr = msk_px[(int64_t)tap * g.S_o];
   };
   struct Fac { float wl[ND], wh[ND], sl[ND], sh[ND], mg; } fac;
   auto build = [&](int tap) {   // sampling state of (tap, this lane's pixel) from dl / ml -> St row; CSR counting
+    float dl[ND], ml = 1.f;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(&dlr[a]);
+    if (MOD) ml = T::ldf(&mlr);
     int tcd[ND];
     tap_coords<ND>(g, tap, tcd);
     TapCoef<ND, float> tc;

@@ -68,14 +68,14 @@ __global__ __launch_bounds__(256, 2) void hp_fwd_kernel(
   int voff[NC];
   float wgt[NC];
   int st_tap = -1, st_dg = -1;
-  float dl[ND], ml = 1.f;   // prefetched offsets / mask of (pf_tap, pf_dg)
+  typename T::Raw dlr[ND], mlr;   // prefetched offsets / mask of (pf_tap, pf_dg), raw until used
   int pf_tap = -1, pf_dg = -1;
   auto fetch = [&](int tap, int dg) {
     const int64_t seg = (int64_t)b * g.DG + dg;
     const int64_t ob = (seg * (ND * g.K) + ND * tap) * g.S_o + pix;
 #pragma unroll
-    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(offset + ob + (int64_t)a * g.S_o);
-    if (MOD) ml = T::ldf(mask + (seg * g.K + tap) * g.S_o + pix);
+    for (int a = 0; a < ND; ++a) dlr[a] = offset[ob + (int64_t)a * g.S_o];
+    if (MOD) mlr = mask[(seg * g.K + tap) * g.S_o + pix];
     pf_tap = tap;
     pf_dg = dg;
   };
@@ -83,6 +83,10 @@ __global__ __launch_bounds__(256, 2) void hp_fwd_kernel(
     if (pf_tap != tap || pf_dg != dg) fetch(tap, dg);
     int tcd[ND];
     tap_coords<ND>(g, tap, tcd);
+    float dl[ND];
+#pragma unroll
+    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(&dlr[a]);
+    const float ml = MOD ? T::ldf(&mlr) : 1.f;
     TapCoef<ND, float> tc;
     make_tap<ND, float>(g, oc, tcd, dl, false, tc);
     HpCorners<ND> hc;

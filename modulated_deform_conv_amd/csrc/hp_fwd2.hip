@@ -19,6 +19,14 @@
 namespace mdconv {
 
 namespace {
+#ifdef F2_TIMING
+// developer instrumentation (tools/b1_timing.py --fwd2): cycles per phase of the stage loop, summed over all waves
+__device__ unsigned long long g_f2_timing[8];
+#define F2_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define F2_T(slot) do { } while (0)
+#endif
+
 
 constexpr int kStage = 4;    // 16-channel chunks per K stage (= 64 channels = one 128-byte line)
 constexpr int kBtP = 72;     // LDS pitch (16-bit elements) of a pixel row of the B tile: 64 + 8
@@ -90,17 +98,24 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
   const int dg0 = g.DG == 1 ? 0 : (ch_lo * 16) / g.Cdg;
 
   // ---- sampling state: offsets / mask one state ahead, state table in LDS (two slots) ----
-  float dl[ND], ml = 1.f;
+  // The RAW 16-bit values are kept until build(): converting them to float inside fetch() is a use of the load
+  // right where it is issued -- a full memory round trip per sampling state, exposed (with the conversion in
+  // fetch() "state build + fetch" was 22 % / 25 % of the kernel's wave-cycles at cfg5 / cfg3, tools/b1_timing.py).
+  Raw dlr[ND], mlr;
   const Raw *off_px = offset + (int64_t)b * g.DG * (ND * g.K) * g.S_o + pix;
   const Raw *msk_px = MOD ? mask + (int64_t)b * g.DG * g.K * g.S_o + pix : nullptr;
   auto fetch = [&](int tap, int dg) {
     const Raw *op = off_px + (int64_t)(dg * g.K + tap) * ND * g.S_o;
 #pragma unroll
-    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(op + (int64_t)a * g.S_o);
-    if (MOD) ml = T::ldf(msk_px + (int64_t)(dg * g.K + tap) * g.S_o);
+    for (int a = 0; a < ND; ++a) dlr[a] = op[(int64_t)a * g.S_o];
+    if (MOD) mlr = msk_px[(int64_t)(dg * g.K + tap) * g.S_o];
   };
   const int px_base = b * g.S_i;
-  auto build = [&](int tap, int slot) {   // from dl / ml
+  auto build = [&](int tap, int slot) {   // from the fetched offsets / mask
+    float dl[ND], ml = 1.f;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(&dlr[a]);
+    if (MOD) ml = T::ldf(&mlr);
     int tcd[ND];
     tap_coords<ND>(g, tap, tcd);
     TapCoef<ND, float> tc;
@@ -214,6 +229,9 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
   const int *st_lane = St + gp * SW;   // this lane's row of pixel group 0, slot 0
   issue(sa, st_lane, 0, ch_lo * 32);
   const int S = g.K * nst;
+#ifdef F2_TIMING
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#endif
   for (int s = 0; s < S; ++s) {
     const int ch0 = ch_lo + st * kStage;
     U4 *Ab = As + ((s & 1) * kStage * nmax) * 64 + lane;
@@ -230,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
       if (st2 >= nst) { st2 = 0; ++tap2; }
       if (tap2 < g.K) fetch(tap2, dg0 + st2 / spd);
     }
+    F2_T(0);   // next sampling state (build) + offset / mask fetch
     const int *sp_cur = st_lane + slot * 32 * SW;
     // ---- gather + interpolate the 4 pixel groups of this stage; the first group of the next stage
     // is requested before the matrix phase ----
@@ -241,10 +260,14 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     interp(sa, 2);
     if (s + 1 < S) issue(sa, st_lane + slot_next * 32 * SW, 0, (ch_lo + st1 * kStage) * 32);
     interp(sb, 3);
+    F2_T(1);   // gathers + interpolation of the 4 pixel groups
     // ---- weights of this stage -> LDS; next stage's weights requested ----
     w_store(Ab, ch0);
+    F2_T(2);   // weights -> LDS (waits for their loads)
     __syncthreads();
+    F2_T(3);   // barrier
     if (s + 1 < S) w_load(tap1, ch_lo + st1 * kStage);
+    F2_T(4);   // weight load issue
     // ---- matrix phase ----
 #ifdef ABL_FWD_NOMFMA   // developer ablation (timing only): no matrix phase (and no A / B fragment reads)
     const int nj = 0;
@@ -267,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
         }
       }
     }
+    F2_T(5);   // matrix phase
     slot = slot_next;
     tap = tap1;
     st = st1;
@@ -285,9 +309,26 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
         }
       }
   }
+#ifdef F2_TIMING
+  F2_T(6);   // epilogue
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_f2_timing[i], t_acc[i]);
+#endif
 }
 
 }  // namespace
+
+#ifdef F2_TIMING
+}  // namespace mdconv
+extern "C" void mdconv_debug_timing_f2(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdconv::g_f2_timing), sizeof(mdconv::g_f2_timing));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mdconv::g_f2_timing), z, sizeof(z));
+  }
+}
+namespace mdconv {
+#endif
 
 size_t hp_fwd2_lds_bytes(const Geom &g, const HpDims &hd) {
   const int nc = 1 << g.nd;

@@ -16,12 +16,18 @@ gemm2 = "--gemm2" in sys.argv   # needs the B2_TIMING variant of mfma_bwd_weight
 if gemm2:
     buf = (ctypes.c_ulonglong * 8)()
     labels = ["prologue", "commit", "barrier", "tab issue", "MFMAs", "A issue", "gather issue (waits for its tab entry)", "partial stores"]
-read = L.mdconv_debug_timing_b2 if gemm2 else L.mdconv_debug_timing_b1
+fwd2 = "--fwd2" in sys.argv     # F2_TIMING variant of hp_fwd2.hip: the 16-bit forward (runs wl.forward)
+if fwd2:
+    buf = (ctypes.c_ulonglong * 8)()
+    labels = ["state build + fetch", "gathers + interpolation", "weights -> LDS", "barrier", "weight load issue",
+              "matrix phase", "epilogue", "-"]
+read = L.mdconv_debug_timing_f2 if fwd2 else (L.mdconv_debug_timing_b2 if gemm2 else L.mdconv_debug_timing_b1)
 for name in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg2"]):
     wl = bench.Workload(name, "cuda")
-    wl.backward(); torch.cuda.synchronize()
+    run = wl.forward if fwd2 else wl.backward
+    run(); torch.cuda.synchronize()
     read(buf, 1)
-    wl.backward(); torch.cuda.synchronize()
+    run(); torch.cuda.synchronize()
     read(buf, 1)
     tot = float(sum(buf))
     print(name + ": " + "  ".join("%s %.1f%%" % (labels[i], 100.0 * buf[i] / max(tot, 1.0)) for i in range(len(labels))),
