@@ -256,6 +256,13 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     interp(sa, 0);
     issue(sa, sp_cur, 2, ch0 * 32);
     interp(sb, 1);
+#ifndef F2_NO_EARLY_USE
+    // the offsets / mask fetched at the top of this stage are OLDER than the gathers interp(sb, 1) has just waited
+    // for: naming them as used here costs no wait, and build() of the next state does not have to drain the queue
+#pragma unroll
+    for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(dlr[a]));
+    if (MOD) asm volatile("" : "+v"(mlr));
+#endif
     issue(sb, sp_cur, 3, ch0 * 32);
     interp(sa, 2);
     if (s + 1 < S) issue(sa, st_lane + slot_next * 32 * SW, 0, (ch_lo + st1 * kStage) * 32);
