@@ -36,6 +36,14 @@
 namespace mdconv {
 
 namespace {
+#ifdef B3_TIMING
+// developer instrumentation (tools/b1_timing.py --bwd3): cycles per phase of the tap loop, summed over all waves
+__device__ unsigned long long g_b3_timing[8];
+#define B3_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define B3_T(slot) do { } while (0)
+#endif
+
 
 constexpr int kChunkRows = 64;   // grad_out rows staged through LDS at a time (4 k-steps)
 
@@ -88,6 +96,9 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
   const rsrc_t r_col = make_rsrc(colbuf + (size_t)b0 * gcol_img, gcol_img * 2);
   const int S_e = hp_anchor_space(g);
 
+#ifdef B3_TIMING
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#endif
   // ---- W^T slab of tap 0 -> LDS (whole workgroup) ----
   for (int i = tid; i < WTOT; i += 256) Ws[i] = wpb[i];
 
@@ -296,10 +307,12 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
 
   fetch(0);
   __syncthreads();   // W^T slab of tap 0 is in LDS (and every wave is past its grad_out staging)
+  B3_T(6);   // prologue: W^T slab of tap 0, grad_out fragments
   for (int tap = 0; tap < g.K; ++tap) {
     if (wave_live) {
       build(tap);
       if (tap + 1 < g.K) fetch(tap + 1);
+      B3_T(0);   // sampling state + next offsets
       // ---- matrix phase: GEMM-1 per 32-channel block -> Gc ----
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
@@ -316,7 +329,9 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
         *reinterpret_cast<U4 *>(dst + 8) = pack8<T>(g1);
       }
     }
+    B3_T(1);   // matrix phase -> Gc
     __syncthreads();   // B1: every wave is done with this tap's W^T slab
+    B3_T(2);   // barrier B1
     // ---- gather phase (+ the next tap's W^T slab, WPI pieces per iteration) ----
     // piece k of iteration `it`: element tid + (it * WPI + k) * 256 of the slab, loaded at the top of the
     // iteration (unconditionally, from a clamped index: a conditional load into a struct ended up in scratch)
@@ -347,12 +362,31 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
       if (on0) wdst[i0] = w0;
       if (on1) wdst[i1] = w1;
     }
+    B3_T(3);   // gather phase (+ W^T staging)
     if (wave_live) finish(tap);
+    B3_T(4);   // grad_offset / grad_mask
     __syncthreads();   // B2: the next tap's W^T slab is complete
+    B3_T(5);   // barrier B2
   }
+#ifdef B3_TIMING
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_b3_timing[i], t_acc[i]);
+#endif
 }
 
 }  // namespace
+
+#ifdef B3_TIMING
+}  // namespace mdconv
+extern "C" void mdconv_debug_timing_b3(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdconv::g_b3_timing), sizeof(mdconv::g_b3_timing));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mdconv::g_b3_timing), z, sizeof(z));
+  }
+}
+namespace mdconv {
+#endif
 
 size_t hp_bwd3_lds_bytes(const HpDims &hd) {
   const size_t region = (size_t)32 * (hd.Cp + 8) * 2 > (size_t)kChunkRows * kPP * 2 ? (size_t)32 * (hd.Cp + 8) * 2

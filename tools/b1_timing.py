@@ -21,7 +21,11 @@ if fwd2:
     buf = (ctypes.c_ulonglong * 8)()
     labels = ["state build + fetch", "gathers + interpolation", "weights -> LDS", "barrier", "weight load issue",
               "matrix phase", "epilogue", "-"]
-read = L.mdconv_debug_timing_f2 if fwd2 else (L.mdconv_debug_timing_b2 if gemm2 else L.mdconv_debug_timing_b1)
+bwd3 = "--bwd3" in sys.argv     # B3_TIMING variant of hp_bwd3.hip
+if bwd3:
+    buf = (ctypes.c_ulonglong * 8)()
+    labels = ["state build + fetch", "matrix phase", "barrier B1", "gather phase", "finish", "barrier B2", "prologue", "-"]
+read = L.mdconv_debug_timing_b3 if bwd3 else L.mdconv_debug_timing_f2 if fwd2 else (L.mdconv_debug_timing_b2 if gemm2 else L.mdconv_debug_timing_b1)
 for name in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg2"]):
     wl = bench.Workload(name, "cuda")
     run = wl.forward if fwd2 else wl.backward
