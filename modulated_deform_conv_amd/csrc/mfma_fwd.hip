@@ -39,6 +39,14 @@
 namespace mdconv {
 
 namespace {
+#ifdef F1_TIMING
+// developer instrumentation (tools/b1_timing.py --fwd): cycles per phase of the chunk loop, summed over all waves
+__device__ unsigned long long g_f1_timing[8];
+#define F1_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define F1_T(slot) do { } while (0)
+#endif
+
 
 template <int ND, bool MOD, int BM, int BN, int WM, int WN, bool PADK>
 __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
@@ -213,9 +221,13 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   float4 ra0[MB][2], ra1[MB][2];
   const int a_last = (T - 1) * slab_bytes;
   int a_soff = 0;   // byte offset of the current chunk in the packed weights
+#ifdef F1_TIMING
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#endif
   load_a(ra0, 0);
   issue(rg0, wc0, 0, 0);
   issue(rg1, wc1, 0, BK);
+  F1_T(0);   // prologue
   for (int tap = 0; tap < g.K; ++tap) {
     for (int c0 = 0; c0 < pd.Cgp; c0 += 2 * BK) {
       // position of the chunk pair two chunks ahead (past the end: harmless re-request)
@@ -224,25 +236,35 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       const int nc0 = wrap ? 0 : c0 + 2 * BK;
       // ---- even chunk: LDS buffer 0, fragments ra0, gathers rg0 ----
       commit(rg0, wc0, c0, Bs);
+      F1_T(1);   // commit: wait for the gathers, interpolate, slab -> LDS
 #ifndef ABL_NOBARRIER
       __syncthreads();
 #endif
+      F1_T(2);   // barrier
       // A first: vmcnt retires in order, so fragments requested AFTER the gathers would make the
       // MFMAs that need them wait for those gathers as well
       load_a(ra1, a_soff + slab_bytes);
+      F1_T(3);   // A issue
       issue(rg0, wc0, ntap, nc0);
       __builtin_amdgcn_sched_barrier(0);   // keep every request above the MFMA phase
+      F1_T(4);   // gather issue (+ sampling state on a tap change)
       mma(ra0, Bs);
+      F1_T(5);   // MFMAs
       // ---- odd chunk: LDS buffer 1, fragments ra1, gathers rg1 ----
       commit(rg1, wc1, c0 + BK, Bs + BK * BN);
+      F1_T(1);
 #ifndef ABL_NOBARRIER
       __syncthreads();
 #endif
+      F1_T(2);
       a_soff += 2 * slab_bytes;
       load_a(ra0, min(a_soff, a_last));
+      F1_T(3);
       issue(rg1, wc1, ntap, nc0 + BK);
       __builtin_amdgcn_sched_barrier(0);
+      F1_T(4);
       mma(ra1, Bs + BK * BN);
+      F1_T(5);
     }
   }
 
@@ -266,6 +288,11 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
         }
     }
   }
+#ifdef F1_TIMING
+  F1_T(6);   // epilogue
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_f1_timing[i], t_acc[i]);
+#endif
 }
 
 template <int ND, bool MOD, int BM, int BN, int WM, int WN>
@@ -298,6 +325,18 @@ int launch_fwd(const Geom &g, const PackDims &pd, const Tensors &t, const float 
 }
 
 }  // namespace
+
+#ifdef F1_TIMING
+}  // namespace mdconv
+extern "C" void mdconv_debug_timing_f1(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdconv::g_f1_timing), sizeof(mdconv::g_f1_timing));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mdconv::g_f1_timing), z, sizeof(z));
+  }
+}
+namespace mdconv {
+#endif
 
 int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
                      hipStream_t stream) {
