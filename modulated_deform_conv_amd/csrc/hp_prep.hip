@@ -39,6 +39,41 @@ __global__ __launch_bounds__(256) void hp_nchw_to_nhwc_kernel(int C, int Cp, int
   }
 }
 
+// The same copy for S a multiple of 8 (and a 16-byte aligned source): 16-byte loads along q (2 per thread instead of
+// 16 two-byte ones), rows written to LDS as loaded, and the transpose done by the LDS itself -- ds_read_b64_tr_b16
+// hands lane i of a 16-lane group column i of a 4 x 16 block, two of them are the 8 channels of one output pixel.
+// Row pitch 80 elements: the four rows of a block start 8 banks apart.  The 16-byte stores of neighbouring lanes
+// land one pixel row apart, which pays for rows of 256 bytes (cfg5, C = 128: 95 -> 61 us) and not for rows of 512
+// (cfg3, C = 256: 36 -> 41 us) -- the launcher picks by row length.  (Vector loads with the two-byte LDS reads of
+// the kernel above: 16-byte aligned rows put a pixel's 8 channel octets in one bank, 49 / 82 us.)
+__global__ __launch_bounds__(256) void hp_nchw_to_nhwc_vec_kernel(int C, int Cp, int S,
+                                                                  const unsigned short *__restrict__ x,
+                                                                  unsigned short *__restrict__ xt) {
+  constexpr int P = 80;
+  __shared__ __attribute__((aligned(16))) unsigned short t[64 * P];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, q0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid >> 3) + 32 * i, u = tid & 7;
+    const int c = c0 + row, q = q0 + u * 8;
+    U4 v = {0, 0, 0, 0};
+    if (c < C && q < S) v = *reinterpret_cast<const U4 *>(x + ((size_t)b * C + c) * S + q);
+    *reinterpret_cast<U4 *>(t + row * P + u * 8) = v;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, i16 = lane & 15;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int combo = pass * 16 + wave * 4 + (lane >> 4);   // (pixel block of 16, channel octet)
+    const int oct = combo & 7, qb = combo >> 3;
+    U4 v;
+    lds_tr2(t + (oct * 8 + (i16 >> 2)) * P + qb * 16 + (i16 & 3) * 4, 4 * P, v);
+    const int q = q0 + qb * 16 + i16, c = c0 + oct * 8;
+    if (q < S && c < Cp) *reinterpret_cast<U4 *>(xt + ((size_t)b * S + q) * Cp + c) = v;
+  }
+}
+
 // forward A operand: wpf[tap][chunk][oblk][lane][8] = W[o = oblk*32 + (lane&31)]
 //                                                      [c = chunk*16 + 8*(lane>>5) + j][tap]
 // dense block-diagonal over conv groups (0 where o and c belong to different groups, or padding).
@@ -198,8 +233,13 @@ __global__ __launch_bounds__(256) void hp_grad_bias_kernel(Geom g, const typenam
 
 int hp_nchw_to_nhwc(const Geom &g, const HpDims &hd, const void *x, void *xt, hipStream_t stream) {
   const dim3 grid((g.S_i + 63) / 64, (hd.Cp + 63) / 64, g.B);
-  hipLaunchKernelGGL(hp_nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
-                     (const unsigned short *)x, (unsigned short *)xt);
+  static const bool vec_env = !(getenv("MDCONV_HP_NHWC_VEC") && atoi(getenv("MDCONV_HP_NHWC_VEC")) == 0);
+  if (vec_env && hd.Cp <= 128 && g.S_i % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL(hp_nchw_to_nhwc_vec_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
+                       (const unsigned short *)x, (unsigned short *)xt);
+  else
+    hipLaunchKernelGGL(hp_nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
+                       (const unsigned short *)x, (unsigned short *)xt);
   return check_launch("hp_nchw_to_nhwc");
 }
 
