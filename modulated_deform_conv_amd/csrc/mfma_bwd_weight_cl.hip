@@ -31,16 +31,18 @@ __device__ unsigned long long g_b2_timing[8];
 //   <2, 2, 1, 1>   64 x 64    C_out <= 64
 //   <2, 2, 2, 1>  128 x 64    C_out <= 128
 //   <4, 1, 2, 2>  256 x 64
+//   <4, 1, 2, 4>  256 x 128  (MDCONV_BW_WIDE=1)
 template <int ND, bool PADN, int WR, int WC, int MB, int NBW>
-__global__ __launch_bounds__(256) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims bd,
+__global__ __launch_bounds__(256, NBW == 4 ? 2 : 1) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims bd,
                                                                  const float *__restrict__ xt,
                                                                  const float *__restrict__ ga,
                                                                  const int *__restrict__ table,
                                                                  float *__restrict__ part) {
-  static_assert(WR * WC == 4 && WC * NBW * 32 == 64, "four waves, 64 input channels");
+  static_assert(WR * WC == 4 && (WC * NBW * 32 == 64 || WC * NBW * 32 == 128), "four waves, 64 or 128 input channels");
   constexpr int NC = 1 << ND;
   constexpr int BK = kBK;
-  constexpr int RM = WR * MB * 32, CN = 64;
+  constexpr int RM = WR * MB * 32, CN = WC * NBW * 32;
+  constexpr int NH = CN / 64;   // 64-channel halves a thread gathers for
   constexpr int kPitch = CN + 1;
   __shared__ __attribute__((aligned(16))) float Bs[2 * BK * kPitch];
 
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims
     m_active = m_active && wo < o_hi && wo + MB * 32 > o_lo;
   }
   const int t_voff = kk * entry_bytes;
-  const int c_voff = (min(c0, g.C - 64) + cq * 4) * 4;   // C is a multiple of 64
+  const int c_voff = (min(c0, g.C - CN) + cq * 4) * 4;   // C is a multiple of the tile width
 
   f32x16 acc[MB][NBW];
 #pragma unroll
@@ -109,21 +111,26 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims
       tb.w[4 * h + 0] = b.x; tb.w[4 * h + 1] = b.y; tb.w[4 * h + 2] = b.z; tb.w[4 * h + 3] = b.w;
     }
   };
-  float4 rg[NC];
+  float4 rg[NH][NC];
   auto gather = [&](const Tab &tb) {
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) rg[ci] = buf_load4(r_xt, tb.off[ci] + c_voff, 0);
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) rg[h][ci] = buf_load4(r_xt, tb.off[ci] + c_voff + h * 256, 0);
   };
   auto commit = [&](const Tab &tb, int t, float *Bb) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {
-      s.x = fmaf(tb.w[ci], rg[ci].x, s.x); s.y = fmaf(tb.w[ci], rg[ci].y, s.y);
-      s.z = fmaf(tb.w[ci], rg[ci].z, s.z); s.w = fmaf(tb.w[ci], rg[ci].w, s.w);
+    for (int h = 0; h < NH; ++h) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        s.x = fmaf(tb.w[ci], rg[h][ci].x, s.x); s.y = fmaf(tb.w[ci], rg[h][ci].y, s.y);
+        s.z = fmaf(tb.w[ci], rg[h][ci].z, s.z); s.w = fmaf(tb.w[ci], rg[h][ci].w, s.w);
+      }
+      if (PADN && t * 16 + kk >= g.N) s = make_float4(0.f, 0.f, 0.f, 0.f);
+      float *d = Bb + kk * kPitch + h * 64 + cq * 4;
+      d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
     }
-    if (PADN && t * 16 + kk >= g.N) s = make_float4(0.f, 0.f, 0.f, 0.f);
-    float *d = Bb + kk * kPitch + cq * 4;
-    d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
   };
   auto load_a = [&](float4 (&ra)[MB][2], int t) {
     if (!m_active) return;
@@ -255,6 +262,7 @@ int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt,
   do {                                                                                          \
     if (bd.wtile == 1) LAUNCH_CL(ND, PADN, 2, 2, 1, 1);                                         \
     else if (bd.wtile == 2) LAUNCH_CL(ND, PADN, 2, 2, 2, 1);                                    \
+    else if (bd.wtile == 4) LAUNCH_CL(ND, PADN, 4, 1, 2, 4);                                    \
     else LAUNCH_CL(ND, PADN, 4, 1, 2, 2);                                                       \
   } while (0)
   if (g.nd == 2) { if (padn) LAUNCH_CL2(2, true); else LAUNCH_CL2(2, false); }

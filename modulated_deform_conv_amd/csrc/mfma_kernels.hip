@@ -109,8 +109,13 @@ BwdDims bwd_dims(const Geom &g) {
   static const int bw_tile_env = getenv("MDCONV_BW_TILE") ? atoi(getenv("MDCONV_BW_TILE")) : 0;
   if (bw_tile_env == 1 && g.O <= 64) bd.wtile = 1;
   if (bd.cl) bd.wtile = g.O <= 64 ? 1 : (g.O <= 128 ? 2 : 3);
+  // 256 x 128 tile (wtile 4): the A fragments and the per-chunk barrier amortised over twice the matrix work
+  // (GEMM-2's time sits in issuing its loads); needs 128-channel blocks inside one
+  // deformable group and one conv group
+  static const int bw_wide_env = getenv("MDCONV_BW_WIDE") ? atoi(getenv("MDCONV_BW_WIDE")) : 0;
+  if (bd.cl && bd.wtile == 3 && bw_wide_env && g.nd == 2 && g.G == 1 && g.C % 128 == 0 && (g.DG == 1 || g.Cdg % 128 == 0)) bd.wtile = 4;   // (3-D: 192 bytes of scratch at two workgroups per CU)
   const int rm = bd.cl ? (bd.wtile == 1 ? 64 : (bd.wtile == 2 ? 128 : 256)) : (bd.wtile ? 64 : 256);
-  const int cn = bd.cl ? 64 : (bd.wtile ? 64 : 32);
+  const int cn = bd.cl ? (bd.wtile == 4 ? 128 : 64) : (bd.wtile ? 64 : 32);
   bd.OgpB = (g.O + rm - 1) / rm * rm;
   bd.mblks = bd.OgpB / 32;
   bd.mtiles = bd.OgpB / rm;
