@@ -39,8 +39,14 @@ def deform_conv_nd(input, offset, mask, weight, bias, stride=1, padding=0, dilat
             base[t, a] = outs[a] * stride[a] - padding[a] + tap[a] * dilation[a]
     base = base.to(dev)
 
-    off = offset.reshape(B, dgroups, K, nd, S_o)
-    p = base[None, None] + off                                         # [B, DG, K, nd, S_o]
+    # offset channel = dg * nd * K + nd * tap + axis, axis order (h, w[, l]), written out channel by channel from
+    # mdeformable_conv.cu:65, 71-72 / deformable_conv3d.cu:92-94, 100-103 (not as one reshape, so that this
+    # statement and the oracle do not share a single reading of the layout; tests/analytic_pins.py pins both)
+    offs = offset.reshape(B, dgroups * nd * K, S_o)
+    p = torch.stack([torch.stack([torch.stack([base[tap, axis][None] + offs[:, dg * nd * K + nd * tap + axis]
+                                               for axis in range(nd)], 1)
+                                  for tap in range(K)], 1)
+                     for dg in range(dgroups)], 1)                     # [B, DG, K, nd, S_o]
     low = torch.floor(p).detach()
     d = p - low
     low = low.long()
@@ -61,7 +67,10 @@ def deform_conv_nd(input, offset, mask, weight, bias, stride=1, padding=0, dilat
         sample = sample + w.reshape(B, dgroups, 1, K * S_o) * g
     sample = sample.reshape(B, dgroups, C // dgroups, K, S_o)
     if mask is not None:
-        sample = sample * mask.reshape(B, dgroups, 1, K, S_o)
+        # mask channel = dg * K + tap (mdeformable_conv.cu:66, 73)
+        mflat = mask.reshape(B, dgroups * K, S_o)
+        mk = torch.stack([torch.stack([mflat[:, dg * K + tap] for tap in range(K)], 1) for dg in range(dgroups)], 1)
+        sample = sample * mk.reshape(B, dgroups, 1, K, S_o)
     col = sample.reshape(B, groups, C // groups, K, S_o)
     wg = weight.reshape(groups, O // groups, C // groups, K)
     out = torch.einsum("gock,bgcks->bgos", wg, col).reshape(B, O, *out_sz)
