@@ -266,6 +266,28 @@ int grid_for(int64_t total) {
 
 }  // namespace
 
+int mfma_bwd_weight_occupancy(int nd, bool padn, int wtile) {
+  static int cache[2][2][2] = {};
+  int &slot = cache[nd == 3][padn][wtile == 1];
+  if (slot) return slot;
+  int n = 0;
+#define OCC_BW(ND, PADN, WR, WC, MB)                                                                           \
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                                          \
+      &n, reinterpret_cast<const void *>(&mfma_bwd_weight_kernel<ND, PADN, WR, WC, MB>), 256, 0)
+#define OCC_BW2(ND, PADN)                                                                                      \
+  do {                                                                                                          \
+    if (wtile == 1) OCC_BW(ND, PADN, 2, 2, 1); else OCC_BW(ND, PADN, 4, 1, 2);                                 \
+  } while (0)
+  if (nd == 2) { if (padn) OCC_BW2(2, true); else OCC_BW2(2, false); }
+  else { if (padn) OCC_BW2(3, true); else OCC_BW2(3, false); }
+#undef OCC_BW2
+#undef OCC_BW
+  (void)hipGetLastError();
+  if (n <= 0) n = 4;
+  slot = n;
+  return n;
+}
+
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, const float *xt,
                         hipStream_t stream) {

@@ -251,6 +251,33 @@ extern "C" void mdconv_debug_timing_b2(unsigned long long *out, int reset) {
 namespace mdconv {
 #endif
 
+// Resident workgroups per CU of the variant that (nd, padn, wtile) selects: hipOccupancy on the very instance, so
+// the split-K count of bwd_dims() follows the register allocation instead of a constant that rots.
+int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile) {
+  static int cache[2][2][5] = {};
+  int &slot = cache[nd == 3][padn][wtile < 0 || wtile > 4 ? 3 : wtile];
+  if (slot) return slot;
+  int n = 0;
+#define OCC_CL(ND, PADN, WR, WC, MB, NBW)                                                                     \
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                                          \
+      &n, reinterpret_cast<const void *>(&mfma_bwd_weight_cl_kernel<ND, PADN, WR, WC, MB, NBW>), 256, 0)
+#define OCC_CL2(ND, PADN)                                                                                      \
+  do {                                                                                                          \
+    if (wtile == 1) OCC_CL(ND, PADN, 2, 2, 1, 1);                                                              \
+    else if (wtile == 2) OCC_CL(ND, PADN, 2, 2, 2, 1);                                                         \
+    else if (wtile == 4) OCC_CL(ND, PADN, 4, 1, 2, 4);                                                         \
+    else OCC_CL(ND, PADN, 4, 1, 2, 2);                                                                         \
+  } while (0)
+  if (nd == 2) { if (padn) OCC_CL2(2, true); else OCC_CL2(2, false); }
+  else { if (padn) OCC_CL2(3, true); else OCC_CL2(3, false); }
+#undef OCC_CL2
+#undef OCC_CL
+  (void)hipGetLastError();
+  if (n <= 0) n = wtile == 4 ? 2 : 3;   // no device (host-only tests): the figures of the committed build
+  slot = n;
+  return n;
+}
+
 int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt, const float *ga,
                               const int *table, float *part, hipStream_t stream) {
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);

@@ -31,6 +31,7 @@
 // consecutive dwords -> no bank conflicts.
 #include "mfma_kernels.hpp"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
                                                        const float *__restrict__ bias,
                                                        const float *__restrict__ offset,
                                                        const float *__restrict__ mask,
-                                                       float *__restrict__ output, int ntm, int ntn) {
+                                                       float *__restrict__ output, int ntm, int ntn,
+                                                       int full_tiles, int tail_ways, float *__restrict__ part) {
   constexpr int BK = kBK;
   constexpr int NC = 1 << ND;
   constexpr int NP = NC / 2;                  // corner pairs along the contiguous axis
@@ -69,8 +71,21 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   __shared__ __attribute__((aligned(16))) float Bs[2 * BK * BN];  // [2][BK][BN]
 
   // ---- tile assignment (XCD-aware: consecutive tiles -> same XCD L2) ----
+  // Blocks [0, full_tiles) own a whole tile (a whole number of dispatch rounds); the tiles left over are cut
+  // into `tail_ways` tap ranges each, so that the last, partly filled round is made of short workgroups
+  // (launch_fwd_tile: cfg2's 3136 tiles over 1024 slots left 64 workgroups running one per CU for a whole
+  // tile time).  A tap-range block writes its partial tile to `part`; fwd_tail_reduce_kernel adds them up.
   const int grp = blockIdx.y;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  int tile, tap_lo = 0, tap_hi = g.K, tail_slot = -1;
+  if ((int)blockIdx.x < full_tiles) {
+    tile = xcd_remap(blockIdx.x, full_tiles);
+  } else {
+    tail_slot = blockIdx.x - full_tiles;
+    const int ti = tail_slot / tail_ways, way = tail_slot - ti * tail_ways;
+    tile = full_tiles + ti;
+    tap_lo = way * g.K / tail_ways;
+    tap_hi = (way + 1) * g.K / tail_ways;
+  }
   const int tn = tile / ntm, tm = tile - tn * ntm;
   const int o0 = tm * BM;
   const int n0 = tn * BN;
@@ -161,6 +176,9 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   };
   // interpolate the gathered corners and publish the B slab of the chunk starting at channel c0
   auto commit = [&](const float2 (&rg)[CPT][NP], const float (&wc)[NC], int c0, float *Bb) {
+#ifdef ABL_NOCOMMIT
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       float val = wc[0] * rg[i][0].x;
@@ -197,7 +215,11 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       for (int s = 0; s < 4; ++s) {
         float b[NB];
 #pragma unroll
+#ifdef ABL_NOLDSREAD
+        for (int n = 0; n < NB; ++n) b[n] = 0.25f * (float)(lane + s);
+#else
         for (int n = 0; n < NB; ++n) b[n] = Bb[(8 * q + s) * BN + n * 32];
+#endif
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
           const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
@@ -220,15 +242,15 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   // ~50 SALU per chunk in integer divisions).
   float4 ra0[MB][2], ra1[MB][2];
   const int a_last = (T - 1) * slab_bytes;
-  int a_soff = 0;   // byte offset of the current chunk in the packed weights
+  int a_soff = tap_lo * cchunks * slab_bytes;   // byte offset of the current chunk in the packed weights
 #ifdef F1_TIMING
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
 #endif
-  load_a(ra0, 0);
-  issue(rg0, wc0, 0, 0);
-  issue(rg1, wc1, 0, BK);
+  load_a(ra0, a_soff);
+  issue(rg0, wc0, tap_lo, 0);
+  issue(rg1, wc1, tap_lo, BK);
   F1_T(0);   // prologue
-  for (int tap = 0; tap < g.K; ++tap) {
+  for (int tap = tap_lo; tap < tap_hi; ++tap) {
     for (int c0 = 0; c0 < pd.Cgp; c0 += 2 * BK) {
       // position of the chunk pair two chunks ahead (past the end: harmless re-request)
       const bool wrap = c0 + 2 * BK >= pd.Cgp;
@@ -268,6 +290,17 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
     }
   }
 
+  if (tail_slot >= 0) {   // partial tile of a tap range: part[tail_slot][o of the tile][pixel of the tile]
+    float *dst = part + (size_t)tail_slot * (BM * BN) + wn0 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dst[(wm0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * BN + q * 32] = acc[mb][q][r];
+    return;
+  }
   // ---- epilogue: + bias, store [B, O, S_o] (lanes 0-31 -> 32 consecutive pixels) ----
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
@@ -295,33 +328,96 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
 #endif
 }
 
-template <int ND, bool MOD, int BM, int BN, int WM, int WN>
-int launch_fwd_tile(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
-                    hipStream_t stream) {
+// output tile of a tail tile = sum of its tap-range partials (+ bias), in a fixed order
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void fwd_tail_reduce_kernel(Geom g, const float *__restrict__ part,
+                                                              const float *__restrict__ bias,
+                                                              float *__restrict__ output, int ntm,
+                                                              int full_tiles, int tail_ways) {
+  const int tile = full_tiles + blockIdx.x;
+  const int tn = tile / ntm, tm = tile - tn * ntm;
+  const float *src = part + (size_t)blockIdx.x * tail_ways * (BM * BN);
+  for (int e = threadIdx.x; e < BM * BN; e += 256) {
+    const int ol = tm * BM + e / BN, n = tn * BN + e % BN;
+    if (ol >= g.Og || n >= g.N) continue;
+    float sacc = src[e];
+    for (int w = 1; w < tail_ways; ++w) sacc += src[(size_t)w * (BM * BN) + e];
+    const int b = n / g.S_o, pix = n - b * g.S_o;
+    output[(int64_t)(b * g.O + ol) * g.S_o + pix] = sacc + (g.with_bias ? bias[ol] : 0.f);
+  }
+}
+
+// Tail plan of a tile grid (see the kernel): tiles that fill whole dispatch rounds, and the number of tap ranges
+// the leftover tiles are cut into so that their workgroups still fit one round.  MDCONV_FWD_TAIL=0 disables.
+void fwd_tail_plan(const Geom &g, int tiles, int slots, int *full_tiles, int *ways) {
+  static const int tail_env = getenv("MDCONV_FWD_TAIL") ? atoi(getenv("MDCONV_FWD_TAIL")) : 1;
+  *full_tiles = tiles;
+  *ways = 1;
+  if (!tail_env || g.G != 1 || g.K < 2 || slots <= 0) return;
+  const int rem = tiles % slots;
+  if (rem == 0) return;
+  int w = slots / rem;
+  if (w > g.K) w = g.K;
+  if (tail_env > 1 && w > tail_env) w = tail_env;   // (experiments: cap the number of ranges)
+  if (w < 2) return;
+  *full_tiles = tiles - rem;
+  *ways = w;
+}
+
+template <int ND, bool MOD, int BM, int BN, int WM, int WN, bool PADK>
+int fwd_tile_slots() {
+  static int slots = 0;
+  if (!slots) {
+    int n = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &n, reinterpret_cast<const void *>(&mfma_fwd_kernel<ND, MOD, BM, BN, WM, WN, PADK>), 256, 0);
+    (void)hipGetLastError();
+    slots = device_cus() * (n > 0 ? n : 3);
+  }
+  return slots;
+}
+
+template <int ND, bool MOD, int BM, int BN, int WM, int WN, bool PADK>
+int launch_fwd_tile_k(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,
+                      hipStream_t stream) {
   const int ntm = (g.Og + BM - 1) / BM;
   const int ntn = (g.N + BN - 1) / BN;
-  dim3 grid(ntm * ntn, g.G);
-  if (g.Cg % (2 * kBK))
-    hipLaunchKernelGGL((mfma_fwd_kernel<ND, MOD, BM, BN, WM, WN, true>), grid, dim3(256), 0, stream,
-                       g, pd, (const float *)t.input, wp, (const float *)t.bias,
-                       (const float *)t.offset, (const float *)t.mask, (float *)t.output, ntm, ntn);
-  else
-    hipLaunchKernelGGL((mfma_fwd_kernel<ND, MOD, BM, BN, WM, WN, false>), grid, dim3(256), 0, stream,
-                       g, pd, (const float *)t.input, wp, (const float *)t.bias,
-                       (const float *)t.offset, (const float *)t.mask, (float *)t.output, ntm, ntn);
-  return check_launch("mfma_fwd");
+  int full_tiles, ways;
+  fwd_tail_plan(g, ntm * ntn, part ? fwd_tile_slots<ND, MOD, BM, BN, WM, WN, PADK>() : 0, &full_tiles, &ways);
+  const int tail_tiles = ntm * ntn - full_tiles;
+  static const bool debug_plan = getenv("MDCONV_DEBUG_PLAN") != nullptr;
+  if (debug_plan)
+    fprintf(stderr, "[mdconv] forward plan: %d x %d tile, %d tiles, slots %d, full %d, tail %d x %d tap ranges\n", BM, BN,
+            ntm * ntn, part ? fwd_tile_slots<ND, MOD, BM, BN, WM, WN, PADK>() : 0, full_tiles, tail_tiles, ways);
+  dim3 grid(full_tiles + tail_tiles * ways, g.G);
+  hipLaunchKernelGGL((mfma_fwd_kernel<ND, MOD, BM, BN, WM, WN, PADK>), grid, dim3(256), 0, stream,
+                     g, pd, (const float *)t.input, wp, (const float *)t.bias,
+                     (const float *)t.offset, (const float *)t.mask, (float *)t.output, ntm, ntn,
+                     full_tiles, ways, part);
+  int rc = check_launch("mfma_fwd");
+  if (rc || tail_tiles == 0) return rc;
+  hipLaunchKernelGGL((fwd_tail_reduce_kernel<BM, BN>), dim3(tail_tiles), dim3(256), 0, stream, g, part,
+                     (const float *)t.bias, (float *)t.output, ntm, full_tiles, ways);
+  return check_launch("fwd_tail_reduce");
+}
+
+template <int ND, bool MOD, int BM, int BN, int WM, int WN>
+int launch_fwd_tile(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,
+                    hipStream_t stream) {
+  if (g.Cg % (2 * kBK)) return launch_fwd_tile_k<ND, MOD, BM, BN, WM, WN, true>(g, pd, t, wp, part, stream);
+  return launch_fwd_tile_k<ND, MOD, BM, BN, WM, WN, false>(g, pd, t, wp, part, stream);
 }
 
 template <int ND, bool MOD>
-int launch_fwd(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+int launch_fwd(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,
                hipStream_t stream) {
   static const char *const v = getenv("MDCONV_FWD_TILE");   // tuning knob: "256x32" | "256x64" (read once)
   if (pd.BM == 256) {
-    if (v && !strcmp(v, "256x64")) return launch_fwd_tile<ND, MOD, 256, 64, 64, 64>(g, pd, t, wp, stream);
-    return launch_fwd_tile<ND, MOD, 256, 32, 64, 32>(g, pd, t, wp, stream);
+    if (v && !strcmp(v, "256x64")) return launch_fwd_tile<ND, MOD, 256, 64, 64, 64>(g, pd, t, wp, part, stream);
+    return launch_fwd_tile<ND, MOD, 256, 32, 64, 32>(g, pd, t, wp, part, stream);
   }
-  if (pd.BM == 128) return launch_fwd_tile<ND, MOD, 128, 64, 64, 32>(g, pd, t, wp, stream);
-  return launch_fwd_tile<ND, MOD, 64, 128, 64, 32>(g, pd, t, wp, stream);
+  if (pd.BM == 128) return launch_fwd_tile<ND, MOD, 128, 64, 64, 32>(g, pd, t, wp, part, stream);
+  return launch_fwd_tile<ND, MOD, 64, 128, 64, 32>(g, pd, t, wp, part, stream);
 }
 
 }  // namespace
@@ -338,13 +434,19 @@ extern "C" void mdconv_debug_timing_f1(unsigned long long *out, int reset) {
 namespace mdconv {
 #endif
 
-int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+// scratch for the tap-range partials of the tail tiles: at most one partial tile (every tile shape is 8192
+// floats) per resident workgroup, 5 of them per CU at the very most
+size_t fwd_tail_bytes(const Geom &g) {
+  return g.G == 1 && g.K >= 2 ? (size_t)device_cus() * 5 * 8192 * sizeof(float) : 0;
+}
+
+int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,
                      hipStream_t stream) {
   if (g.nd == 2)
-    return g.modulated ? launch_fwd<2, true>(g, pd, t, wp, stream)
-                       : launch_fwd<2, false>(g, pd, t, wp, stream);
-  return g.modulated ? launch_fwd<3, true>(g, pd, t, wp, stream)
-                     : launch_fwd<3, false>(g, pd, t, wp, stream);
+    return g.modulated ? launch_fwd<2, true>(g, pd, t, wp, part, stream)
+                       : launch_fwd<2, false>(g, pd, t, wp, part, stream);
+  return g.modulated ? launch_fwd<3, true>(g, pd, t, wp, part, stream)
+                     : launch_fwd<3, false>(g, pd, t, wp, part, stream);
 }
 
 }  // namespace mdconv

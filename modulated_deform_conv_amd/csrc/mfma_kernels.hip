@@ -2,6 +2,7 @@
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <atomic>
@@ -59,6 +60,21 @@ __global__ __launch_bounds__(256) void zero_halfwords_kernel(unsigned short *__r
 }
 
 }  // namespace
+
+int device_cus() {
+  static std::atomic<int> cus{0};
+  int n = cus.load(std::memory_order_relaxed);
+  if (n) return n;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    n = prop.multiProcessorCount;
+  else
+    n = 256;
+  (void)hipGetLastError();
+  cus.store(n, std::memory_order_relaxed);
+  return n;
+}
 
 int zero_bytes(void *p, size_t bytes, hipStream_t s) {
   if (bytes == 0 || p == nullptr) return MDCONV_OK;
@@ -123,11 +139,25 @@ BwdDims bwd_dims(const Geom &g) {
   bd.cblks = bd.Cp / cn;
   const int col_tiles = bd.mtiles * g.K * bd.cblks;
   const int pairs = bd.Np / 32;
-  int splits = (1024 + col_tiles - 1) / col_tiles;       // ~4 workgroups per CU
+  // Split-K so that the grid is ONE full dispatch round: every workgroup does the same work, so a grid of
+  // 1.36 x the resident slots (cfg2 in round 3: 36 column tiles x 29 splits = 1044 workgroups on 256 CUs x 3)
+  // runs its last 276 workgroups one per CU at half the matrix rate -- 0.68 of peak where the steady state
+  // reaches 0.8+.  slots = CUs x resident workgroups of the instance that will run (hipOccupancy).
+  // MDCONV_BW_SPLITS overrides (experiments).
+  const bool padn = bd.Np != g.N;
+  const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile) : mfma_bwd_weight_occupancy(g.nd, padn, bd.wtile);
+  const int slots = device_cus() * occ;
+  int splits = slots / col_tiles;
+  static const int splits_env = getenv("MDCONV_BW_SPLITS") ? atoi(getenv("MDCONV_BW_SPLITS")) : 0;
+  if (splits_env > 0) splits = splits_env;
   if (splits > pairs) splits = pairs;
   if (splits < 1) splits = 1;
   bd.pairs_per_split = (pairs + splits - 1) / splits;
   bd.splits = (pairs + bd.pairs_per_split - 1) / bd.pairs_per_split;
+  static const bool debug_plan = getenv("MDCONV_DEBUG_PLAN") != nullptr;
+  if (debug_plan)
+    fprintf(stderr, "[mdconv] GEMM-2 plan: cl %d wtile %d col_tiles %d occ %d slots %d splits %d x %d pairs\n", bd.cl,
+            bd.wtile, col_tiles, occ, slots, bd.splits, bd.pairs_per_split);
   bd.ochunks = (g.O + 63) / 64 * 4;   // K loop of GEMM-1 is unrolled 4x
   bd.waves_c = g.C > 128 ? 4 : (g.C > 64 ? 2 : 1);
   bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
@@ -226,6 +256,7 @@ size_t core_bytes_for(const Geom &gc, bool backward) {
   const PackDims pd = pack_dims(gc);
   size_t n = align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float));
   if (fwd_channels_last(gc)) n += align_up(fwd_cl_bytes(gc));   // NHWC copy of the input chunk
+  else n += align_up(fwd_tail_bytes(gc));                       // tap-range partials of the last dispatch round
   return n;
 }
 
@@ -356,10 +387,11 @@ bool get_fork(hipStream_t stream, Fork *out) {
 // On by default: cfg2 3.68 -> 3.40 ms per step (GEMM-2 1.06 -> 1.10 ms, the 0.33 ms of CSR build +
 // gather disappear under it); round 1 had measured a loss with the NCHW GEMM-2, whose gathers kept
 // the L2 as busy as the col2im gather does -- the channels-last GEMM-2 leaves the L2 mostly idle.
-bool bwd_fork_enabled() {
+int bwd_fork_mode() {
   static const int on = getenv("MDCONV_BWD_FORK") ? atoi(getenv("MDCONV_BWD_FORK")) : 1;
-  return on != 0;
+  return on;
 }
+bool bwd_fork_enabled() { return bwd_fork_mode() != 0; }
 
 // fp32 backward of one chunk (all kernels accumulate into the grad_* pointers of `t`).
 // Order on the caller's stream:
@@ -405,14 +437,21 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
     if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
     if (weights_final && (rc = record_weight_ready(stream))) return rc;
   }
+  const bool gemm2_first = fork && bwd_fork_mode() == 2;   // (experiment: GEMM-2 enqueued before the gather)
+  if (gemm2_first) {
+    if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
+    if (weights_final && (rc = record_weight_ready(stream))) return rc;
+  }
   if ((rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, gs))) return rc;
   profile_mark(3, true, gs, bd.sample_keyed ? (bd.two_pass ? "col2im3d_sums_kernel" : "col2im3d_kernel") : "col2im_gather_kernel");
   rc = col2im_f32(g, bd, t, gcol, rowptr, entries, (float *)(base + bd.off_sums), gs);
   profile_mark(3, false, gs);
   if (rc) return rc;
   if (fork) {
-    if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
-    if (weights_final && (rc = record_weight_ready(stream))) return rc;
+    if (!gemm2_first) {
+      if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
+      if (weights_final && (rc = record_weight_ready(stream))) return rc;
+    }
     if (hipEventRecord(fk.join, fk.side) != hipSuccess || hipStreamWaitEvent(stream, fk.join, 0) != hipSuccess) {
       set_error("backward join failed");
       return MDCONV_ELAUNCH;
@@ -558,7 +597,8 @@ static int native_forward(const Geom &g, int dtype, const Tensors &t, void *ws, 
       float *xt = (float *)(base + align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float)));
       rc = mfma_forward_cl_f32(gc, pd, tc, wp, xt, stream);
     } else {
-      rc = mfma_forward_f32(gc, pd, tc, wp, stream);
+      float *part = (float *)(base + align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float)));
+      rc = mfma_forward_f32(gc, pd, tc, wp, fwd_tail_bytes(gc) ? part : nullptr, stream);
     }
     profile_mark(0, false, stream);
     if (rc) return rc;

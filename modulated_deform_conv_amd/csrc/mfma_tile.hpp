@@ -102,7 +102,9 @@ BwdDims bwd_dims(const Geom &g);
 // wq : [G][K][Ogp][Cgp]  (tap-major, input channel contiguous)   -- backward GEMM-1 operand
 int pack_weights_f32(const Geom &g, const PackDims &pd, const float *weight, float *wp, float *wq,
                      hipStream_t stream);
-int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+// part: scratch of fwd_tail_bytes(g) for the tap-range partials of the last dispatch round (nullptr = no tail split)
+size_t fwd_tail_bytes(const Geom &g);
+int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,
                      hipStream_t stream);
 // channels-last gathers (mfma_fwd_cl.hip): xt = scratch for the NHWC copy of the input
 bool fwd_channels_last(const Geom &g);
@@ -114,6 +116,11 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
                         hipStream_t stream);
 int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt, const float *ga,
                               const int *table, float *part, hipStream_t stream);
+// resident workgroups per CU of the GEMM-2 instance a shape selects (hipOccupancy, cached); device_cus() = CUs of
+// the current device (256 on MI355X; the same figure without a device, for host-only callers)
+int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile);
+int mfma_bwd_weight_occupancy(int nd, bool padn, int wtile);
+int device_cus();
 bool bwd_channels_last(const Geom &g);
 int nchw_to_nhwc_f32(const Geom &g, const float *x, float *xt, hipStream_t stream);
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);

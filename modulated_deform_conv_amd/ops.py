@@ -80,8 +80,8 @@ def _validate(input, offset, mask, weight, bias, stride, padding, dilation, grou
     if any(t.dtype != input.dtype for t in tensors):
         raise RuntimeError("deform_conv: all tensors must share one dtype, got %s"
                            % [str(t.dtype) for t in tensors])
-    if input.dtype not in (torch.float32, torch.float16, torch.float64):
-        raise RuntimeError("deform_conv: dtype must be float32 / float16 / float64, got %s" % input.dtype)
+    if input.dtype not in (torch.float32, torch.float16, torch.float64, torch.bfloat16):   # = MDCONV_CUDA._DTYPES
+        raise RuntimeError("deform_conv: dtype must be float32 / float16 / bfloat16 / float64, got %s" % input.dtype)
     if any(t.device != input.device for t in tensors):
         raise RuntimeError("deform_conv: all tensors must be on one device")
     return nd, osz
@@ -90,6 +90,12 @@ def _validate(input, offset, mask, weight, bias, stride, padding, dilation, grou
 def _geometry(weight, stride, padding, dilation, groups, deformable_groups, in_step, with_bias):
     return tuple(weight.shape[2:]) + tuple(stride) + tuple(padding) + tuple(dilation) + \
         (groups, deformable_groups, in_step, with_bias)
+
+
+def _input_layout(input):
+    """A dense channels-last 16-bit `input` goes to the entry points as it is: they gather from that layout where the
+    kernels of the direction take it and make their own contiguous copy where not (MDCONV_CUDA._layout)."""
+    return input if MDCONV_CUDA._is_channels_last(input) else input.contiguous()
 
 
 def _entry(nd, modulated, backward):
@@ -104,7 +110,7 @@ def deform_conv(input: torch.Tensor, offset: torch.Tensor, mask: Optional[torch.
                 in_step: int) -> torch.Tensor:
     nd, osz = _validate(input, offset, mask, weight, bias, stride, padding, dilation, groups,
                         deformable_groups, in_step)
-    input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
+    input, offset, weight = _input_layout(input), offset.contiguous(), weight.contiguous()
     mask = None if mask is None else mask.contiguous()
     b = input.new_empty(0) if bias is None else bias.contiguous()
     geo = _geometry(weight, stride, padding, dilation, groups, deformable_groups, in_step,
@@ -112,7 +118,7 @@ def deform_conv(input: torch.Tensor, offset: torch.Tensor, mask: Optional[torch.
     fn = _entry(nd, mask is not None, False)
     if mask is not None and nd == 2:   # the one export that allocates its result
         return fn(input, weight, b, offset, mask, *geo)
-    out = input.new_empty([input.shape[0], weight.shape[0]] + osz)
+    out = torch.empty([input.shape[0], weight.shape[0]] + osz, dtype=input.dtype, device=input.device)
     if mask is not None:
         fn(input, weight, b, offset, mask, out, *geo)
     else:
@@ -141,7 +147,7 @@ def deform_conv_backward(grad_output: torch.Tensor, input: torch.Tensor, offset:
     nd, _ = _validate(input, offset, mask, weight, bias, stride, padding, dilation, groups,
                       deformable_groups, in_step, grad_output)
     grad_output = grad_output.contiguous()
-    input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
+    input, offset, weight = _input_layout(input), offset.contiguous(), weight.contiguous()
     mask = None if mask is None else mask.contiguous()
     b = input.new_empty(0) if bias is None else bias.contiguous()
     geo = _geometry(weight, stride, padding, dilation, groups, deformable_groups, in_step,
