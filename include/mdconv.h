@@ -98,7 +98,7 @@ int mdconv_last_kernels(void);
 /* Per-kernel timing for benchmarks: when enabled, the four dominant kernels are bracketed by HIP
  * events ON THE CALLER'S STREAM.  After a stream/device synchronise, mdconv_profile_read() returns
  * the number of launches of kernel `which` (0 = forward GEMM, 1 = backward data GEMM [the fused
- * backward kernel of the 16-bit path], 2 = backward weight GEMM, 3 = grad_input gather) recorded
+ * backward kernel of the 16-bit path], 2 = backward weight GEMM, 3 = grad_input gather, 4 = coordinate gradients [fp32 split drain]) recorded
  * since the last reset and their total duration in ms; mdconv_profile_name() the name of the kernel
  * variant that ran in that slot last (as rocprofv3 prints it, without template arguments). */
 int mdconv_profile_enable(int on);

@@ -97,7 +97,7 @@ def last_kernels():
     return {0: "none", 1: "direct", 2: "f32", 3: "hp"}[lib().mdconv_last_kernels()]
 
 
-PROFILE_SLOTS = 4   # forward GEMM, backward data GEMM, backward weight GEMM, grad_input gather
+PROFILE_SLOTS = 5   # forward GEMM, backward data GEMM, backward weight GEMM, grad_input gather
 
 
 class overwrite_grads:

@@ -114,8 +114,15 @@ __device__ unsigned long long g_b1_timing[12];
 #define B1_T(slot) do { } while (0)
 #endif
 
-template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL>
-__global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
+#ifndef B1_MINWAVES
+#define B1_MINWAVES 2
+#endif
+// PURE: GEMM-1 and the grad_col stream only (+ packed grad_out and grad_bias partials): the corner sums, tap table
+// and counting live in mfma_coord.hip (coord_grad_kernel / tap_prepass_kernel), which run BESIDE the two GEMMs
+// instead of inside this one (round 4: the fused drain kept this kernel at 0.69 of the matrix peak with 253
+// registers; without it the same loop measures 0.88-0.92 ms at cfg2 against 1.08).
+template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL, bool PURE = false>
+__global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
@@ -357,6 +364,10 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   // inverted scatter map (first pass of the CSR build, csr_pass_kernel<.., false> otherwise):
   // fire-and-forget integer atomics that disappear under the MFMAs.
   auto new_tap_state = [&](int tapp, int dgp, bool count) {
+    if constexpr (PURE) {
+      gc_voff = pp.live ? ((((pp.b * g.K + tapp) * g.S_o + pp.pix) * g.C) + 4 * kh) * 4 : kOob;
+      return;
+    }
     int tcd[ND];
     tap_coords<ND>(g, tapp, tcd);
     TapCoef<ND, float> tc;
@@ -445,6 +456,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   // row); channels-last: [quad of 4 rows][corner] float4 (one 16-byte load per corner and quad).
   struct Batch { float f[RB * NC]; };
   auto gather = [&](int q, int cbase_p, Batch &v) {
+    if constexpr (PURE) return;
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
     if (CL) {
       // Line-wide gathers: batch q covers one half of the wave's 32 pixels (16, all 64 channels) and
@@ -546,6 +558,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       buf_store4(r_gc, vo, cu4 * 4, accp[mb][r0 + 4 * gq], accp[mb][r0 + 4 * gq + 1],
                  accp[mb][r0 + 4 * gq + 2], accp[mb][r0 + 4 * gq + 3]);
     }
+    if constexpr (PURE) return;
     // padded channels have grad_col == 0 exactly (zero weight rows), no predicate needed
 #pragma unroll
     for (int rr = 0; rr < RB; ++rr) {
@@ -593,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
   // LDS; `flush` (end of a tap group / of the tile / of the unit range) writes the group out ----
   int grp_lo = (u0 % g.K) % kTapGroup;   // first slot of the current tap group held in `red`
   auto finish_tap = [&](int tapp, int blk, bool flush_ok, bool last) {
+    if constexpr (PURE) return;
     float goff[ND], gm = 0.f;
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) gm = fmaf(w[ci], S[ci], gm);
@@ -721,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
       B1_T(11);  // ga emission, grad_bias partials
     }
     B1_T(1);
-    if (pass == 0 || per_block) {
+    if (!PURE && (pass == 0 || per_block)) {
       const int dg = per_block ? min((pass * WAVES_C + wc) * 64, g.C - 1) / g.Cdg : 0;
       const int64_t seg = (int64_t)pc.b * g.DG + dg;
       const int64_t ob = (seg * (ND * g.K) + ND * tap) * g.S_o + pc.pix;
@@ -1219,25 +1233,34 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
                       const float *xt, hipStream_t stream) {
   // cnt: per-(image, deformable group, input pixel) counters (zeroed by csr_zero_f32), counted
   // by GEMM-1 (CSR pass 1)
-#define LAUNCH_BD_(ND, MOD, WC, QPQ, CL)                                                        \
+#define LAUNCH_BD_(ND, MOD, WC, QPQ, CL, PURE)                                                      \
   do {                                                                                          \
     const int bnp = 32 * (4 / WC);                                                              \
     const int ntiles = (g.N + bnp - 1) / bnp;                                                   \
     const size_t lds = bwd_data_lds_bytes(g, bd);                                               \
     if (lds > 64 * 1024) {                                                                      \
-      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, \
+      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, PURE>, \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; } \
     }                                                                                           \
     /* complete dispatch rounds of one-tile workgroups (2 per CU by registers, fewer by LDS),  */ \
     /* then the units of the leftover tiles spread over one more, shorter, round              */ \
-    const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;                                           \
+    static const int percu_env = getenv("MDCONV_BD_PERCU") ? atoi(getenv("MDCONV_BD_PERCU")) : 0; \
+    static int occ_q = 0;   /* resident workgroups per CU of this instance at this LDS size */   \
+    if (occ_q == 0) {                                                                           \
+      int nq = 0;                                                                               \
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                       \
+          &nq, (const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, PURE>, 256, lds);       \
+      (void)hipGetLastError();                                                                  \
+      occ_q = nq > 0 ? nq : (lds * 2 <= 160 * 1024 ? 2 : 1);                                    \
+    }                                                                                           \
+    const int per_cu = percu_env > 0 ? percu_env : occ_q;                                       \
     const int slots = num_cus() * per_cu;                                                       \
     static const int tpw_env = getenv("MDCONV_BD_TPW") ? atoi(getenv("MDCONV_BD_TPW")) : 2;     \
     const int tpw = tpw_env > 0 ? tpw_env : 1;   /* whole tiles per workgroup of the full rounds */ \
     const int n_full = ntiles / (slots * tpw) * slots;                                          \
     const int n_tail = (int)std::min<int64_t>((int64_t)(ntiles - n_full * tpw) * g.K, slots);   \
-    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>), dim3(n_full + n_tail),    \
+    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, PURE>), dim3(n_full + n_tail), \
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
@@ -1247,8 +1270,9 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
 /* channels-last drain only where it pays (3-D) */                                                \
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
   do {                                                                                          \
-    if (xt != nullptr && bd.cl_drain) LAUNCH_BD_(ND, MOD, WC, QPQ, true);                       \
-    else LAUNCH_BD_(ND, MOD, WC, QPQ, false);                                                   \
+    if (bd.split_drain) LAUNCH_BD_(ND, false, WC, QPQ, false, true);                            \
+    else if (xt != nullptr && bd.cl_drain) LAUNCH_BD_(ND, MOD, WC, QPQ, true, false);           \
+    else LAUNCH_BD_(ND, MOD, WC, QPQ, false, false);                                            \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \

@@ -17,10 +17,10 @@ namespace {
 std::atomic<bool> g_prof_on{false};
 std::mutex g_prof_mu;
 struct ProfPair { hipEvent_t a, b; };
-constexpr int kProfSlots = 4;   // forward GEMM, backward data GEMM, backward weight GEMM, grad_input gather
+constexpr int kProfSlots = 5;   // forward GEMM, backward data GEMM, backward weight GEMM, grad_input gather, coordinate gradients
 std::vector<ProfPair> g_prof[kProfSlots];
-size_t g_prof_used[kProfSlots] = {0, 0, 0, 0};
-const char *g_prof_name[kProfSlots] = {"", "", "", ""};
+size_t g_prof_used[kProfSlots] = {0, 0, 0, 0, 0};
+const char *g_prof_name[kProfSlots] = {"", "", "", "", ""};
 
 // W[g*Og + o][c][tap]  ->  wp (MFMA-fragment order, mfma_tile.hpp) and wq[g][tap][o][c], zero padded.
 __global__ __launch_bounds__(256) void pack_weights_kernel(Geom g, PackDims pd,
@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(Geom g, PackDims pd,
 }
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool bwd_fork_enabled();   // defined with the fork / join helpers below
 
 // scratch and gradients are cleared by kernels rather than hipMemsetAsync: memset nodes made HIP
 // graph replay fault (tools/graph_check.py), and a plain kernel sequence captures cleanly
@@ -146,7 +148,12 @@ BwdDims bwd_dims(const Geom &g) {
   // MDCONV_BW_SPLITS overrides (experiments).
   const bool padn = bd.Np != g.N;
   const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile) : mfma_bwd_weight_occupancy(g.nd, padn, bd.wtile);
-  const int slots = device_cus() * occ;
+  // ... minus one per CU when the grad_input gather runs beside this kernel on the forked stream: a full round of
+  // 164-register workgroups leaves the gather no wave slot until the round retires, and the two tails then run one
+  // after the other (cfg2, 36 column tiles: 21 splits = 756 workgroups -> GEMM-2 1.00 ms then gather 0.30 ms,
+  // backward 2.35 ms; 14 splits = 504 workgroups, two per CU -> both done after 0.96 ms, backward 2.25 ms)
+  const int occ_run = bwd_fork_enabled() && occ > 1 ? occ - 1 : occ;
+  const int slots = device_cus() * occ_run;
   int splits = slots / col_tiles;
   static const int splits_env = getenv("MDCONV_BW_SPLITS") ? atoi(getenv("MDCONV_BW_SPLITS")) : 0;
   if (splits_env > 0) splits = splits_env;
@@ -182,11 +189,17 @@ BwdDims bwd_dims(const Geom &g) {
     const bool straight = g.nd == 2 && g.G == 1 && nquads % nbatch == 0 && nquads / nbatch <= 2;
     static const int bd_cl_env = getenv("MDCONV_BD_CL") ? atoi(getenv("MDCONV_BD_CL")) : -1;
     bd.cl_drain = bd.cl;
+    // split drain (mfma_coord.hip; opt-in, MDCONV_BD_SPLIT=1): possible whenever the backward has the
+    // channels-last copy (the coordinate-gradient kernel gathers from it) and a deformable group is a whole number of
+    // 64-channel steps or the only group.  Measured SLOWER than the fused kernel: see DESIGN.md section 4.0.
+    static const int bd_split_env = getenv("MDCONV_BD_SPLIT") ? atoi(getenv("MDCONV_BD_SPLIT")) : 0;
+    bd.split_drain = (bd.cl && bd_split_env != 0 && (g.DG == 1 || g.Cdg % 64 == 0)) ? 1 : 0;
     size_red();
     if (bd.cl && straight && (bd_cl_env == 0 || (bd_cl_env < 0 && bwd_data_lds_bytes(g, bd) > 80 * 1024))) {
       bd.cl_drain = 0;
       size_red();
     }
+    if (bd.split_drain) { bd.cl_drain = 0; bd.red_floats = 0; bd.tap_group = 9; }
   }
   const int nc = 1 << g.nd;
   size_t off = 0;
@@ -351,7 +364,7 @@ int narrow(int dtype, const float *src, void *dst, int64_t n, bool accum, hipStr
 // grad_input gather (CSR build + col2im, HBM-bound) needs GEMM-1's grad_col and counters only, GEMM-2
 // (matrix-bound) needs GEMM-1's packed grad_out and tap table only.  One side stream and two events
 // per (device, caller stream), created on first use and kept (bounded like the weights-ready events).
-struct Fork { hipStream_t side; hipEvent_t fork, join; };
+struct Fork { hipStream_t side; hipEvent_t fork, join, table, gemm1; };
 std::mutex g_fork_mu;
 std::vector<std::pair<std::pair<int, hipStream_t>, Fork>> g_forks;
 bool get_fork(hipStream_t stream, Fork *out) {
@@ -363,6 +376,8 @@ bool get_fork(hipStream_t stream, Fork *out) {
   if (g_forks.size() >= 64) {
     (void)hipEventDestroy(g_forks.front().second.fork);
     (void)hipEventDestroy(g_forks.front().second.join);
+    (void)hipEventDestroy(g_forks.front().second.table);
+    (void)hipEventDestroy(g_forks.front().second.gemm1);
     (void)hipStreamDestroy(g_forks.front().second.side);
     g_forks.erase(g_forks.begin());
   }
@@ -377,7 +392,9 @@ bool get_fork(hipStream_t stream, Fork *out) {
   const int prio = prio_env < 0 ? greatest : (prio_env > 0 ? least : 0);
   if (hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, prio) != hipSuccess) return false;
   if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&f.table, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&f.gemm1, hipEventDisableTiming) != hipSuccess)
     return false;
   g_forks.push_back({{dev, stream}, f});
   *out = f;
@@ -420,6 +437,60 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   // channels-last copy of the input for the 3-D gathers of GEMM-1's drain and of GEMM-2
   float *xt = bd.cl ? (float *)(base + bd.off_xt) : nullptr;
   if (bd.cl && (rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream))) return rc;
+  if (bd.split_drain) {
+    // Split drain (mfma_coord.hip).  Two chains, joined before the return:
+    //   caller's stream:  GEMM-1 (pure: grad_col stream, packed grad_out, grad_bias partials) -> GEMM-2 -> reduce
+    //   side stream:      tap table + counting -> scan -> fill   [offset / mask only: beside GEMM-1]
+    //                     -> coordinate gradients -> grad_input gather   [need grad_col: beside GEMM-2]
+    // GEMM-2 waits for the tap table, the coordinate gradients for GEMM-1.  Without the fork (MDCONV_BWD_FORK=0 or
+    // no side stream) the same kernels run one after the other.
+    Fork fk;
+    const bool fork = bwd_fork_enabled() && get_fork(stream, &fk);
+    hipStream_t ss = fork ? fk.side : stream;
+    auto hip_ok = [](hipError_t e) { return e == hipSuccess; };
+    if (fork && !(hip_ok(hipEventRecord(fk.fork, stream)) && hip_ok(hipStreamWaitEvent(fk.side, fk.fork, 0)))) {
+      set_error("backward fork failed");
+      return MDCONV_ELAUNCH;
+    }
+    rc = tap_prepass_f32(g, bd, t, cnt, table, ss);
+    if (!rc && fork && !hip_ok(hipEventRecord(fk.table, fk.side))) { set_error("backward fork failed"); rc = MDCONV_ELAUNCH; }
+    if (!rc) rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, ss);
+    if (!rc) {
+      profile_mark(1, true, stream, "mfma_bwd_data_kernel");
+      rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, stream);
+      profile_mark(1, false, stream);
+    }
+    if (!rc && fork &&
+        !(hip_ok(hipEventRecord(fk.gemm1, stream)) && hip_ok(hipStreamWaitEvent(fk.side, fk.gemm1, 0)) &&
+          hip_ok(hipStreamWaitEvent(stream, fk.table, 0)))) {
+      set_error("backward fork failed");
+      rc = MDCONV_ELAUNCH;
+    }
+    auto shadow = [&]() {
+      int r;
+      profile_mark(4, true, ss, "coord_grad_kernel");
+      r = coord_grad_f32(g, bd, t, gcol, xt, ss);
+      profile_mark(4, false, ss);
+      if (r) return r;
+      profile_mark(3, true, ss, bd.sample_keyed ? (bd.two_pass ? "col2im3d_sums_kernel" : "col2im3d_kernel") : "col2im_gather_kernel");
+      r = col2im_f32(g, bd, t, gcol, rowptr, entries, (float *)(base + bd.off_sums), ss);
+      profile_mark(3, false, ss);
+      return r;
+    };
+    // enqueue order = dispatch order when both queues are ready: MDCONV_BWD_FORK=2 puts GEMM-2 first
+    const bool gemm2_first = fork && bwd_fork_mode() == 2;
+    if (!rc && !gemm2_first) rc = shadow();
+    if (!rc) rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream);
+    if (!rc && weights_final) rc = record_weight_ready(stream);
+    if (!rc && gemm2_first) rc = shadow();
+    // join on every path once the side stream has work (an unjoined fork would leave the side stream writing the
+    // caller's buffers after the return, and an open capture invalid)
+    if (fork && !(hip_ok(hipEventRecord(fk.join, fk.side)) && hip_ok(hipStreamWaitEvent(stream, fk.join, 0))) && !rc) {
+      set_error("backward join failed");
+      rc = MDCONV_ELAUNCH;
+    }
+    return rc;
+  }
   profile_mark(1, true, stream, "mfma_bwd_data_kernel");
   rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, stream);
   profile_mark(1, false, stream);

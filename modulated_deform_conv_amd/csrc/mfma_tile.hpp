@@ -84,6 +84,8 @@ struct BwdDims {
   int red_floats;       // GEMM-1: floats of the grad_offset / grad_mask reduction buffer in LDS
   int tap_group;        // GEMM-1: taps per flush of that buffer (9; 3 where LDS is short)
   int cl_drain;         // GEMM-1 drains through the channels-last copy (line-wide gathers)
+  int split_drain;      // GEMM-1 is the pure GEMM + grad_col stream; tap table / counting and the coordinate
+                        // gradients are their own kernels (mfma_coord.hip) beside the GEMMs
   int sample_keyed;     // scatter lists: 1 = one entry per SAMPLE (3-D, mfma_csr3d.hip), 0 = per corner pair
   int S_e;              // list heads per (image, deformable group): anchor space (3-D) or S_i
   size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
@@ -133,6 +135,11 @@ int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, 
                   void *entries, hipStream_t stream);
 int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol,
                const int *rowptr, const void *entries, float *sums, hipStream_t stream);
+// split drain (mfma_coord.hip): tap table for the channels-last GEMM-2 + the counting pass of the scatter lists,
+// and grad_offset / grad_mask from the grad_col rows and the channels-last input copy
+int tap_prepass_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, int *table, hipStream_t stream);
+int coord_grad_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol, const float *xt,
+                   hipStream_t stream);
 // 3-D: scatter lists keyed by sample (mfma_csr3d.hip)
 int csr_fill3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cursor,
                    const int *rowptr, void *entries, hipStream_t stream);

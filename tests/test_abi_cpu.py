@@ -131,7 +131,9 @@ def test_workspace_plan_and_layout_query_without_gpu(capi):
     cl = lambda d, bwd: L.mdconv_input_layout_supported(ctypes.byref(d), 1, bwd)
     cfg2 = _plan_desc(capi, 2, capi.F32, 32, 256, 256, (56, 56))
     n, K = 32 * 56 * 56, 9
-    assert ws(cfg2, 0) == 256 * 256 * K * 4                                  # packed weights only: no column buffer
+    # packed weights + at most one 32 KB partial tile per resident workgroup for the tap ranges of the last dispatch
+    # round (mfma_fwd.hip: 256 CUs x <= 5 workgroups): no column buffer (925 MB in the reference, mdeformable_conv.cu:159)
+    assert 256 * 256 * K * 4 <= ws(cfg2, 0) <= 256 * 256 * K * 4 + 256 * 5 * 32768 + 512
     assert ws(cfg2, 1) >= n * K * 256 * 4 and ws(cfg2, 1) < 1.5 * n * K * 256 * 4   # grad_col rows + lists + tables
     assert cl(cfg2, 0) == 0 and cl(cfg2, 1) == 0                             # fp32: reference layout only
     cfg5 = _plan_desc(capi, 3, capi.F16, 8, 128, 128, (16, 64, 64), dil=2)
