@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
       const int c = c_lo + cl, q = q0 + ql;
       if (c < min(c_end, g.C) && q < g.S_i) {
         Raw *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q;
-        const float v = (float)tile[cl * TP + ql];
+        const float v = tile[cl * TP + ql];
         T::stf(dst, g.acc_data ? T::ldf(dst) + v : v);
       }
     }
@@ -247,13 +247,21 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
 #endif
 constexpr int kRunA = 16;   // anchors per run: the carry-in anchor is read twice (1 / 16 of the rows)
 
+// Storage of the partial sums: the tensors' own 16-bit type for fp16 (11 significant bits; two to four of them are
+// added per target), fp32 for bf16 -- 8 bits per partial sum and then cancellation between them was a real loss on
+// grad_input (advisor, round 3), so bf16 rounds ONCE, at the grad_input store, like the one-pass kernel.
+template <typename T> struct SumStore { using type = typename T::Raw; };
+template <> struct SumStore<BF16> { using type = float; };
+
 template <int ND, typename T, int LPD>
 __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, int S_e,
                                                              const typename T::Raw *__restrict__ gcol,
                                                              const int *__restrict__ rowptr,
                                                              const int4 *__restrict__ entries,
-                                                             typename T::Raw *__restrict__ sums) {
+                                                             typename SumStore<T>::type *__restrict__ sums) {
   using Raw = typename T::Raw;
+  using Sum = typename SumStore<T>::type;
+  constexpr bool WIDE = sizeof(Sum) == 4;
   constexpr int L = ND - 1, NS = 1 << L;
   constexpr int NQ = 64 / LPD, RUNS = 4 * NQ;
   constexpr int UB = HP_C2I_UB;            // rows per load group; two groups are in flight
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * 2;
   const bool chan_on = r * 8 < cseg;
   const int c_voff = chan_on ? (dg * cseg + r * 8) * 2 : kHpOob;
-  Raw *out = sums + ((int64_t)seg * S_e * NS) * cseg + r * 8;
+  Sum *out = sums + ((int64_t)seg * S_e * NS) * cseg + r * 8;
   // The lists of consecutive anchors are contiguous in `entries`, so a run streams ONE entry range --
   // from the carry-in anchor a_lo - 1 (only its column + 1 part lands in this run) to a_last -- in
   // batches of LPD entries, rows loaded UB at a time with two groups in flight; an entry names its
@@ -290,8 +298,15 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   auto flush = [&]() {   // anchor cur_a is complete: write its sums (not for the carry-in anchor), shift the column carry
     if (cur_a >= a_lo && chan_on) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
-        *reinterpret_cast<U4 *>(out + ((int64_t)cur_a * NS + s) * cseg) = pack8<T>(cur[s]);
+      for (int s = 0; s < NS; ++s) {
+        Sum *o = out + ((int64_t)cur_a * NS + s) * cseg;
+        if constexpr (WIDE) {
+          reinterpret_cast<float4 *>(o)[0] = make_float4(cur[s][0], cur[s][1], cur[s][2], cur[s][3]);
+          reinterpret_cast<float4 *>(o)[1] = make_float4(cur[s][4], cur[s][5], cur[s][6], cur[s][7]);
+        } else {
+          *reinterpret_cast<U4 *>(o) = pack8<T>(cur[s]);
+        }
+      }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -365,12 +380,14 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
 // consecutive targets x 64 channels, lanes = (target, channel octet), LDS transpose to [B, C, S_i]
 template <int ND, typename T>
 __global__ __launch_bounds__(256) void hp_col2im_combine_kernel(Geom g, HpDims hd, int S_e,
-                                                                const typename T::Raw *__restrict__ sums,
+                                                                const typename SumStore<T>::type *__restrict__ sums,
                                                                 typename T::Raw *__restrict__ grad_input) {
   using Raw = typename T::Raw;
+  using Sum = typename SumStore<T>::type;
+  constexpr bool WIDE = sizeof(Sum) == 4;
   constexpr int L = ND - 1, NS = 1 << L;
-  constexpr int QT = 64, CW = 64, TP = QT + 2;
-  __shared__ Raw tile[CW * TP];
+  constexpr int QT = 64, CW = 64, TP = QT + 1;
+  __shared__ float tile[CW * TP];   // fp32: the stencil sum is rounded once, at the grad_input store
   const int qtiles = (g.S_i + QT - 1) / QT;
   const int b = blockIdx.x / qtiles, q0 = (blockIdx.x - b * qtiles) * QT;
   const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;
@@ -390,19 +407,26 @@ __global__ __launch_bounds__(256) void hp_col2im_combine_kernel(Geom g, HpDims h
 #pragma unroll
         for (int a = L; a > 0; --a) { tc[a] = rem % g.in_sz[a]; rem /= g.in_sz[a]; }
         tc[0] = rem;
-        const Raw *base = sums + ((int64_t)(b * g.DG + dg) * S_e * NS) * cseg + cl;
+        const Sum *base = sums + ((int64_t)(b * g.DG + dg) * S_e * NS) * cseg + cl;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           int er = 0;
 #pragma unroll
           for (int ax = 0; ax < L; ++ax) er = er * (g.in_sz[ax] + 1) + tc[ax] + ((s >> (L - 1 - ax)) & 1);
-          const U4 v = *reinterpret_cast<const U4 *>(base + (((int64_t)er * W + tc[L]) * NS + s) * cseg);
-          mac8<T>(acc, v, 1.f);
+          const Sum *src = base + (((int64_t)er * W + tc[L]) * NS + s) * cseg;
+          if constexpr (WIDE) {
+            const float4 v0 = reinterpret_cast<const float4 *>(src)[0], v1 = reinterpret_cast<const float4 *>(src)[1];
+            acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
+            acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+          } else {
+            const U4 v = *reinterpret_cast<const U4 *>(src);
+            mac8<T>(acc, v, 1.f);
+          }
         }
       }
-      Raw *tp = tile + ((threadIdx.x & 7) * 8) * TP + ql;
+      float *tp = tile + ((threadIdx.x & 7) * 8) * TP + ql;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) T::stf(tp + k * TP, acc[k]);
+      for (int k = 0; k < 8; ++k) tp[k * TP] = acc[k];
     }
     __syncthreads();
     for (int x = threadIdx.x; x < CW * QT; x += 256) {
@@ -486,7 +510,7 @@ static int launch_col2im2(const Geom &g, const HpDims &hd, const Tensors &t, con
     const int runs = 4 * (64 / LPD);                                                             \
     hipLaunchKernelGGL((hp_col2im_sums_kernel<ND, T, LPD>),                                      \
                        dim3(g.B * g.DG * ((runs_per_seg + runs - 1) / runs)), dim3(256), 0, stream, g, hd, S_e, \
-                       (const Raw *)gcol, rowptr, (const int4 *)entries, (Raw *)sums);           \
+                       (const Raw *)gcol, rowptr, (const int4 *)entries, (typename SumStore<T>::type *)sums); \
   } while (0)
   if (lanes <= 4) HP_C2S(4);
   else if (lanes <= 8) HP_C2S(8);
@@ -497,13 +521,13 @@ static int launch_col2im2(const Geom &g, const HpDims &hd, const Tensors &t, con
   int rc = check_launch("hp_col2im_sums");
   if (rc) return rc;
   hipLaunchKernelGGL((hp_col2im_combine_kernel<ND, T>), dim3(g.B * ((g.S_i + 63) / 64)), dim3(256), 0, stream, g, hd,
-                     S_e, (const Raw *)sums, (Raw *)t.grad_input);
+                     S_e, (const typename SumStore<T>::type *)sums, (Raw *)t.grad_input);
   return check_launch("hp_col2im_combine");
 }
 
-size_t hp_col2im_sums_bytes(const Geom &g, const HpDims &hd) {
+size_t hp_col2im_sums_bytes(const Geom &g, const HpDims &hd, int dtype) {
   const size_t cseg = g.DG == 1 ? hd.Cp : g.Cdg;
-  return (size_t)g.B * g.DG * hp_anchor_space(g) * (1 << (g.nd - 1)) * cseg * 2;
+  return (size_t)g.B * g.DG * hp_anchor_space(g) * (1 << (g.nd - 1)) * cseg * (dtype == MDCONV_BF16 ? 4 : 2);   // SumStore<T>
 }
 
 int hp_col2im2(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *gcol,

@@ -87,7 +87,7 @@ FwdLayout fwd_layout(const Geom &gc, const HpDims &hd) {
   return L;
 }
 
-BwdLayout bwd_layout(const Geom &gc, const HpDims &hd) {
+BwdLayout bwd_layout(const Geom &gc, const HpDims &hd, int dtype) {
   BwdLayout L;
   size_t off = 0;
   L.off_xt = off;   off += align_up((size_t)gc.B * gc.S_i * hd.Cp * 2);
@@ -104,7 +104,7 @@ BwdLayout bwd_layout(const Geom &gc, const HpDims &hd) {
   L.off_cnt = off;  off += align_up((size_t)gc.B * gc.DG * S_e * sizeof(int));
   L.off_rowptr = off; off += align_up((size_t)gc.B * gc.DG * (S_e + 1) * sizeof(int));
   L.off_entries = off; off += align_up((size_t)gc.B * gc.DG * gc.K * gc.S_o * 32);
-  L.off_sums = off; off += use_col2im2() ? align_up(hp_col2im_sums_bytes(gc, hd)) : 0;
+  L.off_sums = off; off += use_col2im2() ? align_up(hp_col2im_sums_bytes(gc, hd, dtype)) : 0;
   L.total = off;
   return L;
 }
@@ -203,7 +203,7 @@ size_t hp_workspace_bytes(const Geom &g, int dtype, bool backward) {
   if (bc <= 0) return 0;
   const Geom gc = chunk_geom(g, bc);
   hd = hp_dims(gc);
-  return backward ? bwd_layout(gc, hd).total : fwd_layout(gc, hd).total;
+  return backward ? bwd_layout(gc, hd, dtype).total : fwd_layout(gc, hd).total;
 }
 
 // hp_fwd2 with deformable groups: every workgroup row's channel range must start on a group
@@ -264,7 +264,7 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
   if (Bc <= 0) { set_error("hp_backward: no plan"); return MDCONV_EUNSUPPORTED; }
   const Geom g0 = chunk_geom(g, Bc);
   const HpDims hd0 = hp_dims(g0);
-  const BwdLayout L = bwd_layout(g0, hd0);
+  const BwdLayout L = bwd_layout(g0, hd0, dtype);
   char *base = (char *)ws;
   const int nc_off = g.DG * g.nd * g.K, nc_m = g.DG * g.K;
   int rc;

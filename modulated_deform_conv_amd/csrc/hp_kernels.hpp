@@ -63,7 +63,7 @@ int hp_csr_build(const Geom &g, int dtype, const Tensors &t, int *cnt, int *rowp
 int hp_col2im(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *gcol,
               const int *rowptr, const void *entries, hipStream_t stream);
 // two-pass gather: per-anchor partial sums (every grad_col row read once) -> stencil + transpose
-size_t hp_col2im_sums_bytes(const Geom &g, const HpDims &hd);
+size_t hp_col2im_sums_bytes(const Geom &g, const HpDims &hd, int dtype);
 int hp_col2im2(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *gcol,
                const int *rowptr, const void *entries, void *sums, hipStream_t stream);
 

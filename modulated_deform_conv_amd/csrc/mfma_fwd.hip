@@ -355,7 +355,9 @@ void fwd_tail_plan(const Geom &g, int tiles, int slots, int *full_tiles, int *wa
   *ways = 1;
   if (!tail_env || g.G != 1 || g.K < 2 || slots <= 0) return;
   const int rem = tiles % slots;
-  if (rem == 0) return;
+  // only behind at least one full round: a grid that does not fill the chip once gains nothing from more, shorter
+  // workgroups (cfg2 at B = 4, 392 tiles on 1024 slots, every tile cut in two: 0.189 -> 0.211 ms)
+  if (rem == 0 || tiles < slots) return;
   int w = slots / rem;
   if (w > g.K) w = g.K;
   // at most 4 ranges: every range pays a prologue, a partial-tile store and its share of the reduction pass

@@ -62,3 +62,42 @@ def test_16bit_batch_chunk_loop_with_uneven_chunks(which, limit):
     r = subprocess.run([sys.executable, "-c", CHUNK_CODE % ROOT, which], env=env, capture_output=True,
                        text=True, timeout=600)
     assert "HP_CHUNK_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+C2I_CODE = r"""
+import sys
+sys.path.insert(0, %r)
+import torch
+from tests.cases import _c, make_inputs, D3, M3
+from tests.util import run_product
+case = _c("c2i_mdcn3d_s2_c64", M3, 2, 64, 32, (7, 8, 9), 3, stride=2, seed=151)   # stride 2: sums with cancellation
+t = make_inputs(case, dtype=torch.bfloat16, device="cuda")
+_, g, _ = run_product(case, t, "auto")
+torch.cuda.synchronize()
+torch.save(g["grad_input"].float().cpu(), sys.argv[1])
+print("C2I_OK")
+"""
+
+
+def test_bf16_two_pass_gather_rounds_once_like_the_one_pass_gather(tmp_path):
+    """Round-3 advisor (medium): the two-pass grad_input gather rounded every per-anchor partial sum to bf16 and
+    the stencil sum again through a 16-bit LDS tile, where the one-pass kernel accumulates in fp32 and rounds once.
+    bf16 partial sums are fp32 now (hp_col2im.hip, SumStore) and the combine tile is fp32: both kernels round each
+    grad_input element ONCE from an fp32 sum of the same terms (in a different order), so they agree to one bf16
+    ulp of the element plus the fp32 reordering noise -- on a 3-D stride-2 case, whose sums cancel."""
+    import torch
+    res = {}
+    for mode in ("2", "1"):
+        path = str(tmp_path / ("gi_%s.pt" % mode))
+        env = dict(os.environ, MDCONV_HP_C2I=mode)
+        r = subprocess.run([sys.executable, "-c", C2I_CODE % ROOT, path], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert "C2I_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+        res[mode] = torch.load(path)
+    two, one = res["2"].double(), res["1"].double()
+    rms = one.pow(2).mean().sqrt().item()
+    # one bf16 ulp = 2^-7 of the element's binade: |diff| <= 2^-7 |value| + a sliver of the tensor's scale for the
+    # elements whose fp32 sums straddle a rounding boundary near zero
+    bound = 2.0 ** -7 * one.abs() + 2.0 ** -12 * rms
+    assert ((two - one).abs() <= bound).all(), ((two - one).abs() - bound).max().item()
+    assert (two != one).float().mean().item() < 0.2     # and most elements are bit-identical
