@@ -117,12 +117,16 @@ __global__ __launch_bounds__(kThreads) void direct_fwd_kernel(Geom g, int CC, co
       A m = (A)1;
       int pidx[NP];
       A px[NP], py[NP];
+      bool prx[NP], pry[NP];
       for (int cc = 0; cc < cc_n; ++cc) {
         const int c = grp * g.Cg + c0 + cc;
         const int dg = c / g.Cdg;
         if (dg != cur_dg) {
           load_tap<T, ND, MOD, A>(g, offset, mask, b, dg, tap, pix, o, false, tc, m);
-          if (PAIR) make_pairs<ND, A>(g, tc, m, pidx, px, py);   // mask folded into the weights
+          if (PAIR) {
+            make_pairs<ND, A>(g, tc, m, pidx, px, py);   // mask folded into the weights
+            make_pairs_read<ND, A>(g, tc, prx, pry);
+          }
           cur_dg = dg;
         }
         A val = (A)0;
@@ -132,13 +136,15 @@ __global__ __launch_bounds__(kThreads) void direct_fwd_kernel(Geom g, int CC, co
           for (int pi = 0; pi < NP; ++pi) {
             A x, y;
             PairLoad<T>::ld(r_in, (plane_off + (unsigned)pidx[pi]) * (unsigned)sizeof(T), x, y);
-            val += px[pi] * x + py[pi] * y;
+            // an element the reference never reads (weight 0) must not turn a non-finite neighbour into NaN
+            val += (prx[pi] ? px[pi] * x : (A)0) + (pry[pi] ? py[pi] * y : (A)0);
           }
         } else {
           const T *plane = input + (int64_t)(b * g.C + c) * g.S_i;
 #pragma unroll
           for (int ci = 0; ci < (1 << ND); ++ci)
-            val += corner_weight<ND, A>(tc, ci) * (A)ld(plane + corner_index<ND, A>(tc, ci));
+            if (corner_is_read<ND, A>(tc, ci))
+              val += corner_weight<ND, A>(tc, ci) * (A)ld(plane + corner_index<ND, A>(tc, ci));
           val *= m;
         }
         const A *wrow = Ws + (cc * g.K + tap) * TO;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void direct_bwd_data_kernel(
 #pragma unroll
         for (int ci = 0; ci < (1 << ND); ++ci) {
           const int idx = corner_index<ND, A>(tc, ci);
-          v[ci] = (A)ld(input + pbase + idx);
+          v[ci] = corner_is_read<ND, A>(tc, ci) ? (A)ld(input + pbase + idx) : (A)0;   // never read by the reference otherwise
           val += corner_weight<ND, A>(tc, ci) * v[ci];
           const A wa = corner_weight_atom<ND, A>(tc, ci) * m * gcol;  // w * dval, :282-293
           if (wa != (A)0) atomic_add(grad_input + pbase + idx, wa);
@@ -332,7 +338,8 @@ __global__ __launch_bounds__(kThreads) void direct_bwd_weight_kernel(
         A val = (A)0;
 #pragma unroll
         for (int ci = 0; ci < (1 << ND); ++ci)
-          val += corner_weight<ND, A>(tc, ci) * (A)ld(plane + corner_index<ND, A>(tc, ci));
+          if (corner_is_read<ND, A>(tc, ci))
+            val += corner_weight<ND, A>(tc, ci) * (A)ld(plane + corner_index<ND, A>(tc, ci));
         val *= m;  // the re-materialised forward column, mdeformable_conv.cu:316
 #pragma unroll
         for (int t = 0; t < TO; ++t) acc[cc][t] += go[t] * val;

@@ -328,16 +328,21 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
       return last ? record_weight_ready(stream) : MDCONV_OK;
     };
     if (!forked && (rc = weight_tail())) return rc;
-    if ((rc = hp_csr_build(gc, dtype, tc, cnt, rowptr, base + L.off_entries, gs))) return rc;
-    profile_mark(3, true, gs, use_col2im2() ? "hp_col2im_sums_kernel" : "hp_col2im_kernel");
-    rc = use_col2im2() ? hp_col2im2(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, base + L.off_sums, gs)
-                       : hp_col2im(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, gs);
-    profile_mark(3, false, gs);
-    if (rc) return rc;
-    if (forked) {
-      if ((rc = weight_tail())) return rc;
-      if ((rc = join_side_stream(stream))) return rc;
+    rc = hp_csr_build(gc, dtype, tc, cnt, rowptr, base + L.off_entries, gs);
+    if (!rc) {
+      profile_mark(3, true, gs, use_col2im2() ? "hp_col2im_sums_kernel" : "hp_col2im_kernel");
+      rc = use_col2im2() ? hp_col2im2(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, base + L.off_sums, gs)
+                         : hp_col2im(gc, hd, dtype, tc, base + L.off_gcol, rowptr, base + L.off_entries, gs);
+      profile_mark(3, false, gs);
     }
+    if (forked) {
+      // join on EVERY path once the side stream has work: an unjoined fork would leave it reading and writing the
+      // caller's workspace and grad_input after an error return, and an open stream capture invalid
+      if (!rc) rc = weight_tail();
+      const int rj = join_side_stream(stream);
+      if (!rc) rc = rj;
+    }
+    if (rc) return rc;
   }
   return MDCONV_OK;
 }

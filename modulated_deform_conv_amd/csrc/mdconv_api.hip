@@ -340,16 +340,16 @@ int record_weight_ready(hipStream_t stream) {
 static int wait_weight_ready(hipStream_t waiter, bool keyed, hipStream_t producer) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return MDCONV_ELAUNCH;
+  // the wait is enqueued UNDER the lock: record_weight_ready() may evict and destroy the least recently used event
+  // of another stream at any time, and an event copied out of the table could be gone by the time it is waited on
+  std::lock_guard<std::mutex> lock(g_wready_mu);
   hipEvent_t ev = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(g_wready_mu);
-    if (keyed) {
-      auto it = g_wready.find(std::make_pair(dev, producer));
-      if (it != g_wready.end()) ev = it->second.ev;
-    } else {
-      auto it = g_wready_latest.find(dev);
-      if (it != g_wready_latest.end()) ev = it->second;
-    }
+  if (keyed) {
+    auto it = g_wready.find(std::make_pair(dev, producer));
+    if (it != g_wready.end()) ev = it->second.ev;
+  } else {
+    auto it = g_wready_latest.find(dev);
+    if (it != g_wready_latest.end()) ev = it->second;
   }
   if (!ev) {
     set_error(keyed ? "no backward has been issued on that stream of this device"

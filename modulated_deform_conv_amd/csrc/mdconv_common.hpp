@@ -240,6 +240,37 @@ __device__ __forceinline__ void make_pairs_f(const Geom &g, const TapCoef<ND, A>
     wy[pi] = w * yw;
   }
 }
+// A corner is READ by the reference iff it lies inside the image on every axis (mdeformable_conv.cu:9-34) and, in
+// the backward of the files that gate their high loads, passes `d > EPS` (deformable_conv.cu:254-261): vl / vh.
+template <int ND, typename A>
+__device__ __forceinline__ bool corner_is_read(const TapCoef<ND, A> &tc, int ci) {
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) ok = ok && (((ci >> (ND - 1 - a)) & 1) ? tc.vh[a] : tc.vl[a]);
+  return ok;
+}
+// Which elements of the pairs the REFERENCE reads: an element stands for the low and / or the high side of the last
+// axis (clamped sides collapse onto one column), and the reference loads a corner only if it lies inside the image on
+// every axis (mdeformable_conv.cu:9-34, 256-267) and, in the files that gate their high loads, passes `d > EPS`
+// (TapCoef::vl / vh).  Kernels that address corners one by one (channels-last gathers) park the others out of the
+// buffer's range, so a non-finite value in a pixel the reference never touches cannot reach a result through 0 * Inf.
+template <int ND, typename A>
+__device__ __forceinline__ void make_pairs_read(const Geom &g, const TapCoef<ND, A> &tc, bool (&rx)[1 << (ND - 1)],
+                                                bool (&ry)[1 << (ND - 1)]) {
+  constexpr int L = ND - 1;
+  const int lc = tc.last_lc, hc = tc.last_lc + tc.delta[L];
+  const int cl = min(lc, g.in_sz[L] - 2);
+  const bool xr = (lc == cl && tc.vl[L]) || (hc == cl && tc.vh[L]);
+  const bool yr = (lc == cl + 1 && tc.vl[L]) || (hc == cl + 1 && tc.vh[L]);
+#pragma unroll
+  for (int pi = 0; pi < (1 << L); ++pi) {
+    bool row = true;
+#pragma unroll
+    for (int a = 0; a < L; ++a) row = row && (((pi >> (L - 1 - a)) & 1) ? tc.vh[a] : tc.vl[a]);
+    rx[pi] = row && xr;
+    ry[pi] = row && yr;
+  }
+}
 template <int ND, typename A>
 __device__ __forceinline__ void make_pairs(const Geom &g, const TapCoef<ND, A> &tc, A scale,
                                            int (&idx)[1 << (ND - 1)], A (&wx)[1 << (ND - 1)],

@@ -376,6 +376,8 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     int pidx[NP];
     float px[NP], py[NP];
     make_pairs<ND, float>(g, tc, 1.f, pidx, px, py);
+    bool prx[NP], pry[NP];   // elements the reference reads: the channels-last gathers park the others out of range
+    make_pairs_read<ND, float>(g, tc, prx, pry);
     if (ND == 3 && count && kh == 0 && pp.live) {
       // 3-D: one list entry per sample, keyed by its low corner (mfma_csr3d.hip): one atomic
       SampleAnchor<ND> sa;
@@ -404,8 +406,8 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
 #pragma unroll
         for (int pi = 0; pi < NP; ++pi) {
           if (bd.cl) {   // channels-last GEMM-2: byte offsets of both corners into xt[b][q][c]
-            ev[2 * pi] = pp.live ? (pp.b * g.S_i + pidx[pi]) * g.C * 4 : 0;
-            ev[2 * pi + 1] = pp.live ? (pp.b * g.S_i + pidx[pi] + 1) * g.C * 4 : 0;
+            ev[2 * pi] = pp.live && prx[pi] ? (pp.b * g.S_i + pidx[pi]) * g.C * 4 : kOob;
+            ev[2 * pi + 1] = pp.live && pry[pi] ? (pp.b * g.S_i + pidx[pi] + 1) * g.C * 4 : kOob;
           } else {
             ev[pi] = pp.live ? (pp.b * g.C * g.S_i + pidx[pi]) * 4 : 0;
             ev[NP + pi] = 0;
@@ -421,8 +423,8 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
       voff[pi] = (pp.b * g.C * g.S_i + pidx[pi] + 4 * kh * g.S_i) * 4;
-      voffc[2 * pi] = (pp.b * g.S_i + pidx[pi]) * g.C * 4 + 16 * kh;
-      voffc[2 * pi + 1] = voffc[2 * pi] + g.C * 4;
+      voffc[2 * pi] = prx[pi] ? (pp.b * g.S_i + pidx[pi]) * g.C * 4 + 16 * kh : kOob;
+      voffc[2 * pi + 1] = pry[pi] ? (pp.b * g.S_i + pidx[pi] + 1) * g.C * 4 + 16 * kh : kOob;
       w[2 * pi] = px[pi];
       w[2 * pi + 1] = py[pi];
     }

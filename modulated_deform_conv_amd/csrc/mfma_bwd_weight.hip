@@ -290,12 +290,12 @@ int mfma_bwd_weight_occupancy(int nd, bool padn, int wtile) {
 
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, const float *xt,
-                        hipStream_t stream) {
+                        hipStream_t stream, const float *gcol, float *sbuf) {
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
   const bool padn = bd.Np != g.N;
   profile_mark(2, true, stream, bd.cl ? "mfma_bwd_weight_cl_kernel" : "mfma_bwd_weight_kernel");
   if (bd.cl) {
-    const int rcl = mfma_bwd_weight_cl_launch(g, bd, xt, ga, table, part, stream);
+    const int rcl = mfma_bwd_weight_cl_launch(g, bd, xt, ga, table, part, gcol, sbuf, stream);
     if (rcl) return rcl;
   } else {
 #define LAUNCH_BW(ND, PADN, WR, WC, MB)                                                         \

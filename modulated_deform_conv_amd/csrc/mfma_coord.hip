@@ -42,16 +42,6 @@ int grid_for_c(int64_t total) {
   return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
 }
 
-// A corner is READ by the reference iff it lies inside the image on every axis (and, in the files that gate the high
-// loads by d > EPS, its high sides pass the gate): TapCoef::vl / vh carry exactly that for the backward.
-template <int ND>
-__device__ __forceinline__ bool corner_read(const TapCoef<ND, float> &tc, int ci) {
-  bool ok = true;
-#pragma unroll
-  for (int a = 0; a < ND; ++a) ok = ok && (((ci >> (ND - 1 - a)) & 1) ? tc.vh[a] : tc.vl[a]);
-  return ok;
-}
-
 template <int ND, bool MOD>
 __global__ __launch_bounds__(256) void tap_prepass_kernel(Geom g, int Np, int S_e, int sample_keyed,
                                                           const float *__restrict__ offset,
@@ -82,7 +72,7 @@ __global__ __launch_bounds__(256) void tap_prepass_kernel(Geom g, int Np, int S_
       make_tap<ND, float>(g, oc, tcd, delta, true, tc);
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci)
-        if (corner_read<ND>(tc, ci)) {
+        if (corner_is_read<ND, float>(tc, ci)) {
           ev[ci] = (b * g.S_i + corner_index<ND, float>(tc, ci)) * g.C * 4;
           ev[NC + ci] = __float_as_int(corner_weight<ND, float>(tc, ci) * m);
         }
@@ -167,7 +157,7 @@ __global__ __launch_bounds__(256) void coord_grad_kernel(Geom g, const float *__
     float w[NC], dw[ND][NC];
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) {
-      const bool rd = live && corner_read<ND>(tc, ci);
+      const bool rd = live && corner_is_read<ND, float>(tc, ci);
       soff[lane * ROW + ci] = rd ? ((b * g.S_i + corner_index<ND, float>(tc, ci)) * g.C + dg * (steps * 64)) * 4 : kOobC;
       w[ci] = corner_weight<ND, float>(tc, ci);
 #pragma unroll
@@ -236,7 +226,79 @@ __global__ __launch_bounds__(256) void coord_grad_kernel(Geom g, const float *__
   }
 }
 
+// split_drain == 2: the corner sums come from the channels-last GEMM-2 (mfma_bwd_weight_cl.hip, COORD) as one
+// partial per 64-channel block, sbuf[cblk][tap][n][ci]; one thread per (image, deformable group, tap, pixel) adds the
+// blocks of its group and applies the weights.  Same corner order as tap_prepass_kernel's table (corner ci).
+template <int ND, bool MOD>
+__global__ __launch_bounds__(256) void coord_finish_kernel(Geom g, int Np, int bpd, const float *__restrict__ sbuf,
+                                                           const float *__restrict__ offset,
+                                                           const float *__restrict__ mask,
+                                                           float *__restrict__ grad_offset,
+                                                           float *__restrict__ grad_mask) {
+  constexpr int NC = 1 << ND;
+  const int64_t total = (int64_t)g.DG * g.K * g.N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i % g.N);
+    const int tap = (int)((i / g.N) % g.K);
+    const int dg = (int)(i / g.N / g.K);
+    const int b = n / g.S_o, pix = n - b * g.S_o;
+    const int seg = b * g.DG + dg;
+    int oc[ND], tcd[ND];
+    out_coords<ND>(g, pix, oc);
+    tap_coords<ND>(g, tap, tcd);
+    float delta[ND];
+    const int64_t ob = ((int64_t)seg * (ND * g.K) + ND * tap) * g.S_o + pix;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) delta[a] = offset[ob + (int64_t)a * g.S_o];
+    const int64_t mb = ((int64_t)seg * g.K + tap) * g.S_o + pix;
+    const float m = MOD ? mask[mb] : 1.f;
+    TapCoef<ND, float> tc;
+    make_tap<ND, float>(g, oc, tcd, delta, true, tc);
+    const float mg = (!g.range_gate || tc.inside) ? m : 0.f;
+    float S[NC];
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) S[ci] = 0.f;
+    for (int k = 0; k < bpd; ++k) {
+      const float4 *src = reinterpret_cast<const float4 *>(sbuf + (((size_t)(dg * bpd + k) * g.K + tap) * Np + n) * NC);
+#pragma unroll
+      for (int c4 = 0; c4 < NC; c4 += 4) {
+        const float4 v = src[c4 / 4];
+        S[c4] += v.x; S[c4 + 1] += v.y; S[c4 + 2] += v.z; S[c4 + 3] += v.w;
+      }
+    }
+    float gm = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) gm = fmaf(corner_weight<ND, float>(tc, ci), S[ci], gm);
+#pragma unroll
+    for (int a = 0; a < ND; ++a) {
+      float go = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) go = fmaf(corner_dweight<ND, float>(tc, ci, a), S[ci], go);
+      float *dst = grad_offset + ob + (int64_t)a * g.S_o;
+      const float v = go * mg;
+      *dst = g.acc_data ? *dst + v : v;
+    }
+    if (MOD) {
+      float *dst = grad_mask + mb;
+      *dst = g.acc_data ? *dst + gm : gm;
+    }
+  }
+}
+
 }  // namespace
+
+int coord_finish_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *sbuf, hipStream_t stream) {
+  const int64_t total = (int64_t)g.DG * g.K * g.N;
+  const int bpd = g.DG == 1 ? bd.cblks : g.Cdg / 64;   // 64-channel blocks per deformable group
+#define LAUNCH_CF(ND, MOD)                                                                                    \
+  hipLaunchKernelGGL((coord_finish_kernel<ND, MOD>), dim3(grid_for_c(total)), dim3(256), 0, stream, g, bd.Np,  \
+                     bpd, sbuf, (const float *)t.offset, (const float *)t.mask, (float *)t.grad_offset,       \
+                     (float *)t.grad_mask)
+  if (g.nd == 2) { if (g.modulated) LAUNCH_CF(2, true); else LAUNCH_CF(2, false); }
+  else { if (g.modulated) LAUNCH_CF(3, true); else LAUNCH_CF(3, false); }
+#undef LAUNCH_CF
+  return check_launch("coord_finish");
+}
 
 int tap_prepass_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, int *table, hipStream_t stream) {
   const int64_t total = (int64_t)g.DG * g.K * bd.Np;

@@ -134,9 +134,18 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   float2 rg0[CPT][NP], rg1[CPT][NP];
   float wc0[NC], wc1[NC];
   int cur_tap = -1, cur_dg = -1;
+  // Elements of the pairs the reference never reads (a corner outside the image, mdeformable_conv.cu:9-34): their
+  // weight is 0, but 0 * Inf = NaN, so a non-finite value in the neighbouring pixel must not be multiplied at all.
+  // A pair with NO element to read is parked out of the buffer's range (free); a pair with ONE such element -- the
+  // sample sits across the first or the last column -- keeps its load, and the waves that hold such a lane take a
+  // select per loaded element in `commit` (lane masks in SGPRs, one v_cndmask each; wave-uniform branch).
+  typedef unsigned long long lanemask_t;
+  lanemask_t bad[NC], bad0[NC], bad1[NC];   // of the chunk being requested / of the two in-flight sets
+#pragma unroll
+  for (int ci = 0; ci < NC; ++ci) bad[ci] = bad0[ci] = bad1[ci] = 0ull;
 
   // request the gathers of chunk (tap, c0) (and rebuild the sampling state when (tap, dg) changes)
-  auto issue = [&](float2 (&rg)[CPT][NP], float (&wc)[NC], int tap, int c0) {
+  auto issue = [&](float2 (&rg)[CPT][NP], float (&wc)[NC], lanemask_t (&bd)[NC], int tap, int c0) {
     const int dg = g.DG == 1 ? 0 : min(grp * g.Cg + c0, g.C - 1) / g.Cdg;
     if (tap != cur_tap || dg != cur_dg) {
       float delta[ND];
@@ -151,11 +160,15 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       int pidx[NP];
       float pwx[NP], pwy[NP];
       make_pairs<ND, float>(g, tc, m, pidx, pwx, pwy);
+      bool prx[NP], pry[NP];
+      make_pairs_read<ND, float>(g, tc, prx, pry);
 #pragma unroll
       for (int pi = 0; pi < NP; ++pi) {
-        voff[pi] = img_voff + pidx[pi] * 4;
+        voff[pi] = (prx[pi] || pry[pi]) ? img_voff + pidx[pi] * 4 : 0x7ffffff0;
         wgt[2 * pi] = pwx[pi];
         wgt[2 * pi + 1] = pwy[pi];
+        bad[2 * pi] = __ballot(pry[pi] && !prx[pi]);       // loaded beside a wanted neighbour, not to be used
+        bad[2 * pi + 1] = __ballot(prx[pi] && !pry[pi]);
       }
       cur_tap = tap;
       cur_dg = dg;
@@ -172,13 +185,30 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
 #endif
       }
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) wc[ci] = wgt[ci];
+    for (int ci = 0; ci < NC; ++ci) { wc[ci] = wgt[ci]; bd[ci] = bad[ci]; }
   };
   // interpolate the gathered corners and publish the B slab of the chunk starting at channel c0
-  auto commit = [&](const float2 (&rg)[CPT][NP], const float (&wc)[NC], int c0, float *Bb) {
+  auto commit = [&](const float2 (&rgl)[CPT][NP], const float (&wc)[NC], const lanemask_t (&bd)[NC], int c0, float *Bb) {
 #ifdef ABL_NOCOMMIT
     return;
 #endif
+    lanemask_t any_bad = 0ull;
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) any_bad |= bd[ci];
+    float2 rg[CPT][NP];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi) rg[i][pi] = rgl[i][pi];
+    if (any_bad != 0ull) {   // wave-uniform (the masks live in SGPRs)
+#pragma unroll
+      for (int i = 0; i < CPT; ++i)
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+          asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(rg[i][pi].x) : "v"(rgl[i][pi].x), "s"(bd[2 * pi]));
+          asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(rg[i][pi].y) : "v"(rgl[i][pi].y), "s"(bd[2 * pi + 1]));
+        }
+    }
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       float val = wc[0] * rg[i][0].x;
@@ -247,8 +277,8 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
 #endif
   load_a(ra0, a_soff);
-  issue(rg0, wc0, tap_lo, 0);
-  issue(rg1, wc1, tap_lo, BK);
+  issue(rg0, wc0, bad0, tap_lo, 0);
+  issue(rg1, wc1, bad1, tap_lo, BK);
   F1_T(0);   // prologue
   for (int tap = tap_lo; tap < tap_hi; ++tap) {
     for (int c0 = 0; c0 < pd.Cgp; c0 += 2 * BK) {
@@ -257,7 +287,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       const int ntap = wrap ? min(tap + 1, g.K - 1) : tap;
       const int nc0 = wrap ? 0 : c0 + 2 * BK;
       // ---- even chunk: LDS buffer 0, fragments ra0, gathers rg0 ----
-      commit(rg0, wc0, c0, Bs);
+      commit(rg0, wc0, bad0, c0, Bs);
       F1_T(1);   // commit: wait for the gathers, interpolate, slab -> LDS
 #ifndef ABL_NOBARRIER
       __syncthreads();
@@ -267,13 +297,13 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       // MFMAs that need them wait for those gathers as well
       load_a(ra1, a_soff + slab_bytes);
       F1_T(3);   // A issue
-      issue(rg0, wc0, ntap, nc0);
+      issue(rg0, wc0, bad0, ntap, nc0);
       __builtin_amdgcn_sched_barrier(0);   // keep every request above the MFMA phase
       F1_T(4);   // gather issue (+ sampling state on a tap change)
       mma(ra0, Bs);
       F1_T(5);   // MFMAs
       // ---- odd chunk: LDS buffer 1, fragments ra1, gathers rg1 ----
-      commit(rg1, wc1, c0 + BK, Bs + BK * BN);
+      commit(rg1, wc1, bad1, c0 + BK, Bs + BK * BN);
       F1_T(1);
 #ifndef ABL_NOBARRIER
       __syncthreads();
@@ -282,7 +312,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       a_soff += 2 * slab_bytes;
       load_a(ra0, min(a_soff, a_last));
       F1_T(3);
-      issue(rg1, wc1, ntap, nc0 + BK);
+      issue(rg1, wc1, bad1, ntap, nc0 + BK);
       __builtin_amdgcn_sched_barrier(0);
       F1_T(4);
       mma(ra1, Bs + BK * BN);

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
       float *sp = St + ((tap % 3) * BN + tid) * SW;
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci) {
-        sp[ci] = __int_as_float((b_s * g.S_i + corner_index<ND, float>(tc, ci)) * g.C * 4);
+        // corners the reference never reads are parked out of the buffer's range (0 * Inf must not happen)
+        sp[ci] = __int_as_float(corner_is_read<ND, float>(tc, ci)
+                                    ? (b_s * g.S_i + corner_index<ND, float>(tc, ci)) * g.C * 4 : 0x7ffffff0);
         sp[NC + ci] = corner_weight<ND, float>(tc, ci) * ml;
       }
     }

@@ -132,6 +132,21 @@ BwdDims bwd_dims(const Geom &g) {
   // deformable group and one conv group
   static const int bw_wide_env = getenv("MDCONV_BW_WIDE") ? atoi(getenv("MDCONV_BW_WIDE")) : 0;
   if (bd.cl && bd.wtile == 3 && bw_wide_env && g.nd == 2 && g.G == 1 && g.C % 128 == 0 && (g.DG == 1 || g.Cdg % 128 == 0)) bd.wtile = 4;   // (3-D: 192 bytes of scratch at two workgroups per CU)
+  // Drain of GEMM-1 (grad_offset / grad_mask): 0 = fused into GEMM-1 (the default: at cfg2
+  // the fused kernel hides 0.31 ms of drain in 0.18 ms), 1 = own kernel beside GEMM-2 (mfma_coord.hip), 2 = corner
+  // sums inside the channels-last GEMM-2 + a finishing pass (2-D).  Both split forms are parity-green and measured
+  // SLOWER (backward 2.38 / 2.60 ms against 2.22 at cfg2): opt-in experiments, MDCONV_BD_SPLIT = 1 | 2, available
+  // where the backward has the channels-last copy and a deformable group is a whole number of 64-channel blocks.
+  {
+    static const int bd_split_env = getenv("MDCONV_BD_SPLIT") ? atoi(getenv("MDCONV_BD_SPLIT")) : -1;
+    int mode = 0;
+    if (bd.cl && (g.DG == 1 || g.Cdg % 64 == 0)) {
+      mode = bd_split_env >= 0 ? bd_split_env : 0;
+      if (mode == 2 && (g.nd != 2 || bd.wtile == 4)) mode = 0;
+      if (mode < 0 || mode > 2) mode = 0;
+    }
+    bd.split_drain = mode;
+  }
   const int rm = bd.cl ? (bd.wtile == 1 ? 64 : (bd.wtile == 2 ? 128 : 256)) : (bd.wtile ? 64 : 256);
   const int cn = bd.cl ? (bd.wtile == 4 ? 128 : 64) : (bd.wtile ? 64 : 32);
   bd.OgpB = (g.O + rm - 1) / rm * rm;
@@ -147,7 +162,8 @@ BwdDims bwd_dims(const Geom &g) {
   // reaches 0.8+.  slots = CUs x resident workgroups of the instance that will run (hipOccupancy).
   // MDCONV_BW_SPLITS overrides (experiments).
   const bool padn = bd.Np != g.N;
-  const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile) : mfma_bwd_weight_occupancy(g.nd, padn, bd.wtile);
+  const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile, bd.split_drain == 2)
+                        : mfma_bwd_weight_occupancy(g.nd, padn, bd.wtile);
   // ... minus one per CU when the grad_input gather runs beside this kernel on the forked stream: a full round of
   // 164-register workgroups leaves the gather no wave slot until the round retires, and the two tails then run one
   // after the other (cfg2, 36 column tiles: 21 splits = 756 workgroups -> GEMM-2 1.00 ms then gather 0.30 ms,
@@ -189,11 +205,6 @@ BwdDims bwd_dims(const Geom &g) {
     const bool straight = g.nd == 2 && g.G == 1 && nquads % nbatch == 0 && nquads / nbatch <= 2;
     static const int bd_cl_env = getenv("MDCONV_BD_CL") ? atoi(getenv("MDCONV_BD_CL")) : -1;
     bd.cl_drain = bd.cl;
-    // split drain (mfma_coord.hip; opt-in, MDCONV_BD_SPLIT=1): possible whenever the backward has the
-    // channels-last copy (the coordinate-gradient kernel gathers from it) and a deformable group is a whole number of
-    // 64-channel steps or the only group.  Measured SLOWER than the fused kernel: see DESIGN.md section 4.0.
-    static const int bd_split_env = getenv("MDCONV_BD_SPLIT") ? atoi(getenv("MDCONV_BD_SPLIT")) : 0;
-    bd.split_drain = (bd.cl && bd_split_env != 0 && (g.DG == 1 || g.Cdg % 64 == 0)) ? 1 : 0;
     size_red();
     if (bd.cl && straight && (bd_cl_env == 0 || (bd_cl_env < 0 && bwd_data_lds_bytes(g, bd) > 80 * 1024))) {
       bd.cl_drain = 0;
@@ -221,6 +232,7 @@ BwdDims bwd_dims(const Geom &g) {
   static const int c2i_env = getenv("MDCONV_C2I3D") ? atoi(getenv("MDCONV_C2I3D")) : 2;
   bd.two_pass = bd.sample_keyed && c2i_env >= 2 ? 1 : 0;
   bd.off_sums = off; off += bd.two_pass ? align_up(col2im3d_sums_bytes(g)) : 0;
+  bd.off_sbuf = off; off += bd.split_drain == 2 ? align_up((size_t)bd.cblks * g.K * bd.Np * nc * sizeof(float)) : 0;
   bd.off_end = off;
   return bd;
 }
@@ -373,14 +385,9 @@ bool get_fork(hipStream_t stream, Fork *out) {
   std::lock_guard<std::mutex> lock(g_fork_mu);
   for (auto &e : g_forks)
     if (e.first.first == dev && e.first.second == stream) { *out = e.second; return true; }
-  if (g_forks.size() >= 64) {
-    (void)hipEventDestroy(g_forks.front().second.fork);
-    (void)hipEventDestroy(g_forks.front().second.join);
-    (void)hipEventDestroy(g_forks.front().second.table);
-    (void)hipEventDestroy(g_forks.front().second.gemm1);
-    (void)hipStreamDestroy(g_forks.front().second.side);
-    g_forks.erase(g_forks.begin());
-  }
+  // Entries are never destroyed: another host thread may be between fork and join on any of them (advisor,
+  // round 3).  Past 64 distinct (device, stream) callers a new one simply runs its backward unforked.
+  if (g_forks.size() >= 64) return false;
   Fork f;
   // A stream of ANOTHER priority class: HIP multiplexes the streams of one class over a few hardware queues,
   // and once a process holds more streams (RCCL's, after init_process_group) the side stream can land on the
@@ -466,12 +473,16 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
       set_error("backward fork failed");
       rc = MDCONV_ELAUNCH;
     }
+    const bool in_gemm2 = bd.split_drain == 2;
+    float *sbuf = in_gemm2 ? (float *)(base + bd.off_sbuf) : nullptr;
     auto shadow = [&]() {
       int r;
-      profile_mark(4, true, ss, "coord_grad_kernel");
-      r = coord_grad_f32(g, bd, t, gcol, xt, ss);
-      profile_mark(4, false, ss);
-      if (r) return r;
+      if (!in_gemm2) {
+        profile_mark(4, true, ss, "coord_grad_kernel");
+        r = coord_grad_f32(g, bd, t, gcol, xt, ss);
+        profile_mark(4, false, ss);
+        if (r) return r;
+      }
       profile_mark(3, true, ss, bd.sample_keyed ? (bd.two_pass ? "col2im3d_sums_kernel" : "col2im3d_kernel") : "col2im_gather_kernel");
       r = col2im_f32(g, bd, t, gcol, rowptr, entries, (float *)(base + bd.off_sums), ss);
       profile_mark(3, false, ss);
@@ -480,8 +491,13 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
     // enqueue order = dispatch order when both queues are ready: MDCONV_BWD_FORK=2 puts GEMM-2 first
     const bool gemm2_first = fork && bwd_fork_mode() == 2;
     if (!rc && !gemm2_first) rc = shadow();
-    if (!rc) rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream);
+    if (!rc) rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream, in_gemm2 ? gcol : nullptr, sbuf);
     if (!rc && weights_final) rc = record_weight_ready(stream);
+    if (!rc && in_gemm2) {
+      profile_mark(4, true, stream, "coord_finish_kernel");
+      rc = coord_finish_f32(g, bd, t, sbuf, stream);
+      profile_mark(4, false, stream);
+    }
     if (!rc && gemm2_first) rc = shadow();
     // join on every path once the side stream has work (an unjoined fork would leave the side stream writing the
     // caller's buffers after the return, and an open capture invalid)
@@ -509,26 +525,29 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
     if (weights_final && (rc = record_weight_ready(stream))) return rc;
   }
   const bool gemm2_first = fork && bwd_fork_mode() == 2;   // (experiment: GEMM-2 enqueued before the gather)
+  rc = MDCONV_OK;
   if (gemm2_first) {
-    if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
-    if (weights_final && (rc = record_weight_ready(stream))) return rc;
+    rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream);
+    if (!rc && weights_final) rc = record_weight_ready(stream);
   }
-  if ((rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, gs))) return rc;
-  profile_mark(3, true, gs, bd.sample_keyed ? (bd.two_pass ? "col2im3d_sums_kernel" : "col2im3d_kernel") : "col2im_gather_kernel");
-  rc = col2im_f32(g, bd, t, gcol, rowptr, entries, (float *)(base + bd.off_sums), gs);
-  profile_mark(3, false, gs);
-  if (rc) return rc;
+  if (!rc) rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, gs);
+  if (!rc) {
+    profile_mark(3, true, gs, bd.sample_keyed ? (bd.two_pass ? "col2im3d_sums_kernel" : "col2im3d_kernel") : "col2im_gather_kernel");
+    rc = col2im_f32(g, bd, t, gcol, rowptr, entries, (float *)(base + bd.off_sums), gs);
+    profile_mark(3, false, gs);
+  }
   if (fork) {
-    if (!gemm2_first) {
-      if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
-      if (weights_final && (rc = record_weight_ready(stream))) return rc;
+    if (!rc && !gemm2_first) {
+      rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream);
+      if (!rc && weights_final) rc = record_weight_ready(stream);
     }
-    if (hipEventRecord(fk.join, fk.side) != hipSuccess || hipStreamWaitEvent(stream, fk.join, 0) != hipSuccess) {
+    // join on every path after the fork (error returns included): the side stream must not outlive the call
+    if ((hipEventRecord(fk.join, fk.side) != hipSuccess || hipStreamWaitEvent(stream, fk.join, 0) != hipSuccess) && !rc) {
       set_error("backward join failed");
-      return MDCONV_ELAUNCH;
+      rc = MDCONV_ELAUNCH;
     }
   }
-  return MDCONV_OK;
+  return rc;
 }
 
 }  // namespace

@@ -45,6 +45,7 @@ class FusedGradAllReduce:
         self.group = group
         self._flat = None
         self._comm = None
+        self._grouped = None   # None = untried, True / False = the grouped in-place launch works / does not
 
     def _buffer(self, numel, device, dtype):
         dtype = torch.float64 if dtype == torch.float64 else torch.float32   # never below fp32
@@ -58,13 +59,22 @@ class FusedGradAllReduce:
         # RCCL, fp32 / fp64 gradients: both tensors in ONE grouped launch (ncclGroupStart / End), in place --
         # no flat staging buffer, i.e. four copy kernels and their launches less per step (the exchange is
         # 2.4 MB at cfg2: launch latency is all it costs)
-        if (not async_op and grads and all(g.is_cuda and g.is_contiguous() and g.dtype in (torch.float32, torch.float64)
-                                           for g in grads)
+        if (not async_op and grads and self._grouped is not False
+                and all(g.is_cuda and g.is_contiguous() and g.dtype in (torch.float32, torch.float64) for g in grads)
                 and hasattr(dist, "_coalescing_manager") and dist.get_backend(self.group) == "nccl"):
-            with dist._coalescing_manager(group=self.group, device=grads[0].device, async_ops=False):
-                for g in grads:
-                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            return None
+            # `_coalescing_manager` is a private torch API whose signature has changed between releases (2.0:
+            # (group, device, reqs)); a TypeError / AttributeError is raised on ENTERING the context, before any
+            # collective is issued, so falling back to the flat buffer below is safe -- and remembered
+            try:
+                cm = dist._coalescing_manager(group=self.group, device=grads[0].device, async_ops=False)
+            except (TypeError, AttributeError):
+                cm, self._grouped = None, False
+            if cm is not None:
+                with cm:
+                    for g in grads:
+                        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                self._grouped = True
+                return None
         flat = self._buffer(sum(g.numel() for g in grads), grads[0].device, grads[0].dtype)
         off = 0
         for g in grads:

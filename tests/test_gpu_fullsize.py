@@ -95,7 +95,7 @@ def test_cfg2_linearity_shards_instep_determinism(cfg2):
     # (to fp32 re-association: the tiles of the forward's last dispatch round are summed over tap ranges,
     # mfma_fwd.hip, and which tiles those are depends on the batch size -- SURVEY.md section 8e asks for
     # "fp32 reassociation tolerance" between shards and the single-GPU run, not for equal bits)
-    assert_close("output", torch.cat([p[0] for p in parts]), out, 2e-6)
+    assert_close("output", torch.cat([p[0] for p in parts]), out, 1e-5)
     assert_close("grad_input", torch.cat([p[1][0] for p in parts]), g[0], 1e-5)
     assert_close("grad_offset", torch.cat([p[1][1] for p in parts]), g[1], 1e-5)
     assert_close("grad_mask", torch.cat([p[1][2] for p in parts]), g[2], 1e-5)

@@ -210,16 +210,13 @@ def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
 
 
 @pytest.mark.parametrize("path", ["mfma", "direct"])
-@pytest.mark.xfail(strict=True, reason="documented deviation (INTEGRATION.md, Limits): the fp32 kernels fetch "
-                   "corner PAIRS with one load and fold validity into the weights, so the neighbour of an "
-                   "out-of-image corner is read with weight 0 and 0 * Inf = NaN, where the reference never "
-                   "reads it (mdeformable_conv.cu:9-34); masking the values costs a VALU select per loaded "
-                   "element inside the MFMA-bound K loops")
 def test_fp32_non_finite_border_pixel_is_not_read(path):
     """1x1 kernel, x-offset -0.5 everywhere: output column 0 samples between columns -1 (outside, never
     read by the reference) and 0; the fp32 kernels fetch the pair (column 0, column 1) and give column 1
-    the weight 0.  With Inf in input column 1 the reference's column 0 stays finite.  The 16-bit twin of
-    this test (tests/test_gpu_hp.py) passes: those kernels park invalid corners out of the buffer's range."""
+    the weight 0.  With Inf in input column 1 the reference's column 0 stays finite.  Round 4: the forward's
+    pair loads keep their 8 bytes, but the waves that hold such a sample select the unread element away before the
+    multiply (mfma_fwd.hip, `bad` lane masks); pairs with nothing to read, every channels-last gather and the
+    shape-generic kernels park / skip the corner like the 16-bit kernels do (tests/test_gpu_hp.py)."""
     case = CASE_BY_NAME["mfma_mdcn2d_k1_c64_o32"]
     t = make_inputs(case, dtype=torch.float32, device="cuda")
     t["offset"].zero_()
@@ -230,3 +227,39 @@ def test_fp32_non_finite_border_pixel_is_not_read(path):
     want_out, _ = run_oracle(case, t, torch.float32)
     assert torch.isfinite(want_out[0, :, :, 0]).all() and not torch.isfinite(want_out[0, :, :, 1]).any()
     assert torch.equal(torch.isfinite(out.cpu()), torch.isfinite(want_out))
+
+
+def _inf_case(name):
+    from tests.cases import D2, D3, M2, _c
+    return {
+        # channels-last backward (3-D always; 2-D from 16 k output pixels): every gather addresses corners one by one
+        "dcn3d_c64_cl": _c("inf_dcn3d_c64", D3, 1, 64, 32, (5, 6, 5), 3, seed=161),
+        "mdcn2d_c64_cl": _c("inf_mdcn2d_c64", M2, 6, 64, 32, (56, 56), 3, seed=162),
+        # small 2-D shape: the NCHW backward kernels (8-byte pair loads in GEMM-1's drain and in GEMM-2)
+        "mdcn2d_c64_small": _c("inf_mdcn2d_c64_small", M2, 2, 64, 32, (9, 11), 3, seed=163),
+    }[name]
+
+
+@pytest.mark.parametrize("name,path", [
+    ("dcn3d_c64_cl", "mfma"), ("mdcn2d_c64_cl", "mfma"), ("mdcn2d_c64_small", "direct"),
+    pytest.param("mdcn2d_c64_small", "mfma", marks=pytest.mark.xfail(
+        strict=True, reason="documented deviation (INTEGRATION.md, Limits): below 16 k output pixels the fp32 2-D "
+        "backward keeps the NCHW kernels, whose 8-byte pair loads give the neighbour of an out-of-image corner the "
+        "weight 0 (0 * Inf = NaN) in GEMM-1's drain and in GEMM-2; the forward and every channels-last backward "
+        "never read it"))])
+def test_fp32_backward_with_a_non_finite_border_pixel(name, path):
+    """Inf in ONE channel of one border pixel: the gradients that the reference keeps finite stay finite -- a corner
+    outside the image is never read (mdeformable_conv.cu:256-267), and neither is the in-image neighbour that a
+    paired or clamped load would fetch next to it."""
+    case = _inf_case(name)
+    t = make_inputs(case, dtype=torch.float32, device="cuda")
+    nd = len(case["in_sz"])
+    t["input"][(0, 3) + (0,) * (nd - 1) + (1,)] = float("inf")     # second pixel of the first row: a pair's "other" element
+    t["input"][(0, 5) + (0,) * nd] = float("inf")                   # the corner pixel itself
+    out, grads, paths = run_product(case, t, path)
+    want_out, want = run_oracle(case, t, torch.float32)
+    assert paths[1] == path
+    assert torch.equal(torch.isfinite(out.cpu()), torch.isfinite(want_out))
+    for k in ("grad_offset", "grad_mask", "grad_input", "grad_weight"):
+        if want[k] is not None:
+            assert torch.equal(torch.isfinite(grads[k].cpu()), torch.isfinite(want[k])), k
