@@ -132,6 +132,86 @@ class Workload:
         return self.gw, self.gb
 
 
+class _HipClock:
+    """Device plumbing main() needs: synchronise, stamp, profile -- on the GPU."""
+    stub = False
+    dist_backend = "nccl"
+
+    def setup(self, local_rank):
+        import torch
+        torch.cuda.set_device(local_rank)
+        return torch.device("cuda", local_rank)
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def stamp(self):
+        import torch
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def elapsed_ms(self, a, b):
+        return a.elapsed_time(b)
+
+    def workload(self, name, device):
+        return Workload(name, device)
+
+
+class _StubWorkload:
+    """HOST-ONLY stand-in for tests of the launcher / sharding / reporting logic (MDCONV_BENCH_STUB=1,
+    tests/test_bench_cpu.py): same interface as Workload, a step that sleeps in proportion to its batch and returns
+    CPU tensors for the exchange.  It computes nothing and is never used for a reported number."""
+
+    def __init__(self, name, device):
+        import torch
+        cfg = dict(WORKLOADS[name])
+        self.name, self.cfg, self.B = name, cfg, cfg["B"]
+        self.K = 3 ** cfg["nd"]
+        self.n_samples = self.B * cfg["C"] * self.K * math.prod(cfg["sp"])
+        self.gemm_flop = 2.0 * cfg["O"] * (cfg["C"] // cfg["G"]) * self.K * self.B * math.prod(cfg["sp"])
+        self.bytes, self.scale = cfg["bytes"], 1.0
+        self.gw, self.gb = torch.ones(8, 8), torch.ones(8)
+
+    def shard(self, lo, hi):
+        f = (hi - lo) / self.B
+        self.scale *= f
+        self.n_samples = self.n_samples // self.B * (hi - lo)
+        self.gemm_flop *= f
+        self.bytes *= f
+        self.B = hi - lo
+
+    def forward(self):
+        time.sleep(1e-4 * self.B)
+        return self.gw
+
+    def backward(self):
+        time.sleep(2e-4 * self.B)
+        return self.gw.clone(), self.gb.clone()
+
+
+class _StubClock:
+    stub = True
+    dist_backend = "gloo"
+
+    def setup(self, local_rank):
+        import torch
+        return torch.device("cpu")
+
+    def sync(self):
+        pass
+
+    def stamp(self):
+        return time.perf_counter()
+
+    def elapsed_ms(self, a, b):
+        return (b - a) * 1e3
+
+    def workload(self, name, device):
+        return _StubWorkload(name, device)
+
+
 def resolve_world(gpus, env, visible_gpus):
     """How this invocation runs.  -> ("spawn", N): re-execute under torch.distributed.run with N ranks;
     ("run", world, rank, local_rank): run as that rank.  Raises SystemExit (non-zero) when the
@@ -269,7 +349,8 @@ def main():
     args = ap.parse_args()
 
     import torch
-    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    be = _StubClock() if os.environ.get("MDCONV_BENCH_STUB") == "1" else _HipClock()
+    visible = None if be.stub else (torch.cuda.device_count() if torch.cuda.is_available() else 0)
     plan = resolve_world(args.gpus, os.environ, visible)
     if plan[0] == "spawn":
         import socket
@@ -281,24 +362,26 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         os.execv(sys.executable, cmd)
     _, world, rank, local_rank = plan
-    if not torch.cuda.is_available():
+    if not be.stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    use_graph = args.graph if args.graph is not None else args.scaling == "strong"
+    use_graph = (args.graph if args.graph is not None else args.scaling == "strong") and not be.stub
     # under torchrun (RANK set) the collective path is exercised even with one process
     distributed = world > 1 or (os.environ.get("MDCONV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = be.setup(local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"   # the image's default prints a banner on stdout
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # ... and RCCL's warnings go there too: stdout carries ONE line
-        dist.init_process_group("nccl", device_id=device)
+        if be.stub:
+            dist.init_process_group(be.dist_backend)
+        else:
+            dist.init_process_group(be.dist_backend, device_id=device)
 
     from modulated_deform_conv_amd import _capi
     from modulated_deform_conv_amd.distributed import FusedGradAllReduce, shard_bounds
-    wl = Workload("cfg2", device)
+    wl = be.workload("cfg2", device)
     nominal_b = wl.B
     if args.scaling == "strong":
         # global batch 32: this rank's contiguous shard
@@ -342,26 +425,27 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    paths = _capi.last_path()
-    if graph is None:
+    be.sync()
+    paths = "stub" if be.stub else _capi.last_path()
+    if graph is None and not be.stub:
         _capi.profile_enable(True)
         _capi.profile_reset()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    be.sync()
     t0 = time.perf_counter()
-    marks[0].record()
+    marks = [be.stamp()]
     for i in range(args.steps):
         step()
-        marks[i + 1].record()
+        marks.append(be.stamp())
     t_enq = time.perf_counter()
-    torch.cuda.synchronize()
+    be.sync()
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if graph is None:
+    if be.stub:
+        prof, prof_src = {"stub_kernel": (args.steps, 1.0)}, "stub"
+    elif graph is None:
         _capi.profile_enable(False)
         prof, prof_src = _capi.profile_read(), "HIP events around each kernel inside the timed region"
     else:
@@ -386,13 +470,12 @@ def main():
     sustained = None
     if args.sustain_s > 0:
         n_sus = max(args.steps, int(args.sustain_s / max(elapsed / args.steps, 1e-6)))
-        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
+        s0 = be.stamp()
         for _ in range(n_sus):
             step()
-        s1.record()
-        torch.cuda.synchronize()
-        sustained = (s0.elapsed_time(s1) / n_sus, n_sus)
+        s1 = be.stamp()
+        be.sync()
+        sustained = (be.elapsed_ms(s0, s1) / n_sus, n_sus)
 
     if rank != 0:
         if distributed:
@@ -400,14 +483,14 @@ def main():
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms = sorted(be.elapsed_ms(marks[i], marks[i + 1]) for i in range(args.steps))
     global_b = nominal_b * world if args.scaling == "weak" else nominal_b
     value = global_b * (wl.n_samples // wl.B) / (elapsed / args.steps) / 1e9
     # dominant kernel = the profiled kernel with the largest measured average duration
     gemms = {k: v for k, v in prof.items() if "col2im" not in k}
     dom, (dom_n, dom_ms) = max(gemms.items(), key=lambda kv: kv[1][1])
     achieved = wl.gemm_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    traffic, traffic_src = measured_traffic(dom)
+    traffic, traffic_src = (None, "stub") if be.stub else measured_traffic(dom)
     comp = wl.bytes
     result = {
         "metric": "fwd+bwd GSamples/s, MDCN2d 3x3 C=256 56x56 B=32; %HBM roofline",
@@ -433,11 +516,11 @@ def main():
                          "peak_GBs": HBM_PEAK_GBS,
                          "frac": round(comp / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
-    if world == 1 and not distributed and not args.no_other_configs:
+    if world == 1 and not distributed and not args.no_other_configs and not be.stub:
         del wl
         torch.cuda.empty_cache()
         result["other_configs"] = {n: time_other_config(n, device) for n in ("cfg3", "cfg4", "cfg5")}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not be.stub:
         result["cpu_baseline"] = cpu_baseline()
     print(json.dumps(result))
     if distributed:

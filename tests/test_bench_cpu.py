@@ -59,3 +59,44 @@ def test_workload_table_matches_survey_8d():
         assert c["bytes"] == nbytes
         gemm = 2.0 * c["O"] * (c["C"] // c["G"]) * K * c["B"] * math.prod(c["sp"])
         assert abs(3 * gemm - flop) / flop < 2e-3
+
+
+def _stub_bench(*flags):
+    """bench.py end to end with the host-only stub workload (MDCONV_BENCH_STUB=1: sleeps instead of kernels, gloo
+    instead of RCCL): the launcher, rank / shard arithmetic, barrier + MAX-over-ranks timing and the JSON line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MDCONV_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
+                        "--sustain-s", "0.05", "--no-cpu-baseline"] + list(flags),
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout            # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_rank_launch_shards_and_reports_whole_job_throughput(scaling):
+    """`--gpus 2` without a launcher re-executes under torch.distributed.run with two ranks (here on CPU, gloo);
+    weak: B = 32 per rank, global batch 64; strong: global batch 32 in shards of 16; `value`
+    is the whole job's samples over the MAX-over-ranks time."""
+    d = _stub_bench("--gpus", "2", "--scaling", scaling)
+    per_image = 256 * 9 * 56 * 56
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 4 and d["warmup"] == 1
+    assert d["config"]["global_batch"] == (64 if scaling == "weak" else 32)
+    assert ("B=%d per GPU" % (32 if scaling == "weak" else 16)) in d["config"]["workload"]
+    assert d["config"]["parallelism"] == "dp2 batch-sharded"
+    want = d["config"]["global_batch"] * per_image / (d["ms_per_step"] * 1e-3) / 1e9
+    assert abs(d["value"] - want) / want < 2e-3
+    assert d["sustained_ms_per_step"] > 0 and d["sustained_steps"] >= 4
+    # the stub sleeps 0.3 ms per image: strong-scaling shards must be about twice as fast as the weak ones
+    assert (4.0 < d["ms_per_step"] < 40.0) if scaling == "strong" else (9.0 < d["ms_per_step"] < 60.0)
+
+
+def test_single_rank_stub_line_has_the_contract_fields():
+    d = _stub_bench()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "sustained_ms_per_step"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 32 and d["vs_baseline"] is None
