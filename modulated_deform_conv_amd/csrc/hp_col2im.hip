@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
     SampleAnchor<ND> sa;
     sample_anchor<ND>(g, tc, m, sa);
     if (sa.on) {
-      const int pos = rowptr[(int64_t)seg * (S_e + 1) + sa.qa] + atomicAdd(cursor + (int64_t)seg * S_e + sa.qa, 1);
+      // the counters double as cursors, counted down: no clearing pass between scan and fill
+      const int pos = rowptr[(int64_t)seg * (S_e + 1) + sa.qa] + atomicSub(cursor + (int64_t)seg * S_e + sa.qa, 1) - 1;
       int4 *e = entries + ((int64_t)seg * ((int64_t)g.K * g.S_o) + pos) * 2;
       e[0] = make_int4(tap * g.S_o + pix, __float_as_int(sa.wx), __float_as_int(sa.wy), __float_as_int(sa.rl[0]));
       e[1] = make_int4(__float_as_int(sa.rh[0]), __float_as_int(ND == 3 ? sa.rl[ND - 2] : 0.f),
@@ -259,7 +260,6 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
                                                              const int *__restrict__ rowptr,
                                                              const int4 *__restrict__ entries,
                                                              typename SumStore<T>::type *__restrict__ sums) {
-  using Raw = typename T::Raw;
   using Sum = typename SumStore<T>::type;
   constexpr bool WIDE = sizeof(Sum) == 4;
   constexpr int L = ND - 1, NS = 1 << L;
@@ -481,7 +481,6 @@ int hp_csr_build(const Geom &g, int dtype, const Tensors &t, int *cnt, int *rowp
   hipLaunchKernelGGL(hp_csr_scan_kernel, dim3((S_e + kScanChunk - 1) / kScanChunk, g.B * g.DG), dim3(256), 0, stream,
                      S_e, cnt, rowptr);
   if ((rc = check_launch("hp_csr_scan"))) return rc;
-  if ((rc = hp_csr_zero(g, cnt, stream))) return rc;
 #define HP_CSR(ND, MOD, T)                                                                        \
   hipLaunchKernelGGL((hp_csr_fill_kernel<ND, MOD, T>), dim3(grid_for(samples)), dim3(256), 0, stream, g, S_e, \
                      (const typename T::Raw *)t.offset, (const typename T::Raw *)t.mask, cnt, rowptr,    \

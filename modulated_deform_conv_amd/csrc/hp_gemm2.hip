@@ -70,8 +70,10 @@ __global__ __launch_bounds__(64 * WAVES, MB2 <= 4 ? 3 : 1) void hp_gemm2_kernel(
     int lb = (t_lo * 32) / g.S_o, lp = t_lo * 32 - lb * g.S_o;
     auto load_g = [&](int item, int lb, int lp) -> U4 {
       const int o = item >> 2, oct = item & 3;
-      if (tile_ok)   // images beyond the batch fall out of the buffer's range (zeros)
-        return buf_load4u(r_go, o < g.O ? (o * g.S_o + oct * 8) * 2 : kHpOob, (lb * g.O * g.S_o + lp) * 2);
+      if (tile_ok)   // the scalar offset is NOT part of the range check: images beyond the batch are parked in the
+                     // lane offset like padded channels (they cannot occur while tile_ok implies lb < B; kept explicit)
+        return buf_load4u(r_go, o < g.O && lb < g.B ? (o * g.S_o + oct * 8) * 2 : kHpOob,
+                          (min(lb, g.B - 1) * g.O * g.S_o + lp) * 2);
       int bb = lb, pp = lp + oct * 8;
       while (pp >= g.S_o) { pp -= g.S_o; ++bb; }
       U4 v = {0, 0, 0, 0};

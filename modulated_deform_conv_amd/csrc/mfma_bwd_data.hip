@@ -892,7 +892,9 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(Geom g, const float *__re
     for (int pi = 0; pi < NP; ++pi) {
       if (ux[pi] != 0.f || uy[pi] != 0.f) {
         const int q = aidx[pi];
-        const int pos = rowptr[(int64_t)seg * (g.S_i + 1) + q] + atomicAdd(cursor + (int64_t)seg * g.S_i + q, 1);
+        // the counters double as cursors, counted DOWN: no clearing pass between scan and fill (the order inside a
+        // list is the atomics' arrival order either way)
+        const int pos = rowptr[(int64_t)seg * (g.S_i + 1) + q] + atomicSub(cursor + (int64_t)seg * g.S_i + q, 1) - 1;
         entries[(int64_t)seg * ((int64_t)g.K * g.S_o * NP) + pos] =
             make_int4(tap * g.S_o + pix, __float_as_int(ax[pi]), __float_as_int(ay[pi]), 0);
       }
@@ -1306,13 +1308,10 @@ int csr_zero_f32(const Geom &g, const BwdDims &bd, int *cnt, hipStream_t stream)
 int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, int *rowptr,
                   void *entries, hipStream_t stream) {
   const int64_t samples = (int64_t)g.B * g.DG * g.K * g.S_o;
-  const int64_t cnt_n = (int64_t)g.B * g.DG * bd.S_e;
   int rc;
   hipLaunchKernelGGL(csr_scan_kernel, dim3((bd.S_e + kScanChunk - 1) / kScanChunk, g.B * g.DG), dim3(256), 0,
                      stream, bd.S_e, cnt, rowptr);
   if ((rc = check_launch("csr_scan"))) return rc;
-  hipLaunchKernelGGL(zero_int_kernel, dim3(grid_for(cnt_n)), dim3(256), 0, stream, cnt, cnt_n);
-  if ((rc = check_launch("zero_cnt"))) return rc;
   if (bd.sample_keyed) return csr_fill3d_f32(g, bd, t, cnt, rowptr, entries, stream);
 #define LAUNCH_CSR(ND, MOD)                                                                     \
   hipLaunchKernelGGL((csr_fill_kernel<ND, MOD>), dim3(grid_for(samples)), dim3(256), 0, stream,  \

@@ -219,9 +219,18 @@ __global__ __launch_bounds__(256) void reduce_weight_kernel(Geom g, BwdDims bd,
     const int o = (int)((i / g.Cg) % g.O);
     const int tap = (int)(i / g.Cg / g.O);
     const int c = (o / g.Og) * g.Cg + cl;
+    // four partials in flight (a plain loop left one dependent load per split: 30 us for 33 MB at cfg2); the order
+    // of the additions is fixed, so the result stays bit-reproducible
+    const float *src = part + ((size_t)tap * bd.OgpB + o) * bd.Cp + c;
+    const size_t stride = (size_t)g.K * bd.OgpB * bd.Cp;
     float s = 0.f;
-    for (int sp = 0; sp < bd.splits; ++sp)
-      s += part[((size_t)(sp * g.K + tap) * bd.OgpB + o) * bd.Cp + c];
+    int sp = 0;
+    for (; sp + 4 <= bd.splits; sp += 4) {
+      const float a0 = src[(size_t)sp * stride], a1 = src[(size_t)(sp + 1) * stride];
+      const float a2 = src[(size_t)(sp + 2) * stride], a3 = src[(size_t)(sp + 3) * stride];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; sp < bd.splits; ++sp) s += src[(size_t)sp * stride];
     float *dst = grad_weight + ((int64_t)o * g.Cg + cl) * g.K + tap;
     *dst = g.acc_w ? *dst + s : s;
   }

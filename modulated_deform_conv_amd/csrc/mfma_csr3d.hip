@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void csr_fill3d_kernel(Geom g, int S_e, const 
     SampleAnchor<ND> sa;
     sample_anchor<ND>(g, tc, m, sa);
     if (sa.on) {
-      const int pos = rowptr[(int64_t)seg * (S_e + 1) + sa.qa] + atomicAdd(cursor + (int64_t)seg * S_e + sa.qa, 1);
+      const int pos = rowptr[(int64_t)seg * (S_e + 1) + sa.qa] + atomicSub(cursor + (int64_t)seg * S_e + sa.qa, 1) - 1;   // counters count down
       int4 *e = entries + ((int64_t)seg * ((int64_t)g.K * g.S_o) + pos) * 2;
       e[0] = make_int4(tap * g.S_o + pix, __float_as_int(sa.wx), __float_as_int(sa.wy), __float_as_int(sa.rl[0]));
       e[1] = make_int4(__float_as_int(sa.rh[0]), __float_as_int(sa.rl[1]), __float_as_int(sa.rh[1]), sa.qa);

@@ -810,16 +810,33 @@ bool split_plan(const Geom &g, int dtype, SplitPlan *p) {
   p->total = off + p->sub_bytes;
   return true;
 }
+// strided row copy as a KERNEL, not hipMemcpy2DAsync: memcpy / memset nodes made HIP graph replay fault
+// (see zero_bytes), and the library promises plain kernel sequences that capture cleanly.  Pitches and widths are
+// multiples of 2 bytes (element sizes 2 / 4), 4-byte words where everything is 4-byte aligned.
+template <typename W>
+__global__ __launch_bounds__(256) void copy_rows_kernel(W *__restrict__ dst, int64_t dpitch, const W *__restrict__ src,
+                                                        int64_t spitch, int64_t width, int64_t rows) {
+  const int64_t n = width * rows;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / width, c = i - r * width;
+    dst[r * dpitch + c] = src[r * spitch + c];
+  }
+}
 int copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipStream_t stream) {
   if (width == 0 || rows == 0) return MDCONV_OK;
-  hipError_t e = (dpitch == width && spitch == width)
-                     ? hipMemcpyAsync(dst, src, width * rows, hipMemcpyDeviceToDevice, stream)
-                     : hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, stream);
-  if (e != hipSuccess) {
-    set_error("slice copy failed: %s", hipGetErrorString(e));
-    return MDCONV_ELAUNCH;
-  }
-  return MDCONV_OK;
+  const bool words = ((dpitch | spitch | width) & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 3) == 0;
+  const size_t es = words ? 4 : 2;
+  const int64_t n = (int64_t)(width / es) * (int64_t)rows;
+  const int64_t blocks = (n + 255) / 256;
+  const dim3 grid((unsigned)(blocks > 16384 ? 16384 : blocks));
+  if (words)
+    hipLaunchKernelGGL(copy_rows_kernel<unsigned>, grid, dim3(256), 0, stream, (unsigned *)dst, (int64_t)(dpitch / 4),
+                       (const unsigned *)src, (int64_t)(spitch / 4), (int64_t)(width / 4), (int64_t)rows);
+  else
+    hipLaunchKernelGGL(copy_rows_kernel<unsigned short>, grid, dim3(256), 0, stream, (unsigned short *)dst,
+                       (int64_t)(dpitch / 2), (const unsigned short *)src, (int64_t)(spitch / 2), (int64_t)(width / 2),
+                       (int64_t)rows);
+  return check_launch("copy_rows");
 }
 
 int split_backward(const Geom &g, int dtype, const SplitPlan &p, const Tensors &t, void *ws, hipStream_t stream) {
