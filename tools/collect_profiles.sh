@@ -10,9 +10,9 @@ D=$ROOT/gpurun_out/prof_$1
 rm -rf $D; mkdir -p $D
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.kernel_sources_sha16())" > $D/kernel_sources_sha16.txt
 cd /tmp
-timeout 280 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > $D/bench_stdout.txt 2>&1
-timeout 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D -o pmc_fetch -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
-timeout 280 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D -o pmc_write -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
+timeout 280 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --sustain-s 0 > $D/bench_stdout.txt 2>&1
+timeout 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D -o pmc_fetch -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --sustain-s 0 > /dev/null 2>&1
+timeout 280 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D -o pmc_write -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --sustain-s 0 > /dev/null 2>&1
 cd $ROOT
 timeout 400 python bench.py > $D/bench_full.json 2> $D/bench_full.err
 timeout 200 python bench.py --graph --no-cpu-baseline --no-other-configs > $D/bench_graph.json 2>> $D/bench_full.err

@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 D=$ROOT/gpurun_out/pmc_$2
 mkdir -p $D
 cd /tmp
-timeout 250 rocprofv3 --pmc $1 --output-format csv -d $D -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 250 rocprofv3 --pmc $1 --output-format csv -d $D -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --sustain-s 0 > /dev/null 2>&1
 python3 - <<PY
 import csv, collections, re
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
