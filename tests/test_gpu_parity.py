@@ -263,3 +263,21 @@ def test_fp32_backward_with_a_non_finite_border_pixel(name, path):
     for k in ("grad_offset", "grad_mask", "grad_input", "grad_weight"):
         if want[k] is not None:
             assert torch.equal(torch.isfinite(grads[k].cpu()), torch.isfinite(want[k])), k
+
+
+@pytest.mark.parametrize("O", [16, 40])
+def test_forward_tail_tap_ranges_on_a_ragged_last_tile(O):
+    """More tiles than resident workgroup slots, a last dispatch round that is mostly empty and a ragged last tile:
+    the forward cuts the leftover tiles into tap ranges and adds the partial tiles up (mfma_fwd.hip, fwd_tail_plan).
+    C_out = 16 / 40 select the 64 x 128 tile (800 tiles of 128 pixels on 768 slots); 102 396 pixels are not a
+    multiple of 128, so the last tail tile is partly outside the batch; C_out = 40 also leaves padded rows."""
+    from tests.cases import M2, _c
+    case = _c("tail_mdcn2d_c16", M2, 4, 16, O, (161, 159), 3, seed=171)
+    t = make_inputs(case, dtype=torch.float32, device="cuda")
+    out, grads, paths = run_product(case, t, "mfma")
+    assert paths == ["mfma", "mfma"]
+    want_out, want = run_oracle(case, t, torch.float32)
+    assert_close("output", out, want_out, 1e-4)
+    for k, g in grads.items():
+        if want[k] is not None:
+            assert_close(k, g, want[k], 1e-4)
