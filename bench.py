@@ -501,7 +501,8 @@ def main():
         "sustained_ms_per_step": None if sustained is None else round(sustained[0], 4),
         "sustained_steps": None if sustained is None else sustained[1],
         "launch_mode": "hip graph replay" if graph is not None else "eager (one Python call per entry point)",
-        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+        "data": "STUB -- host-only launcher test, no kernel ran, not a measurement" if be.stub else "synthetic",
         "config": {"workload": "%s, B=%d per GPU, forward+backward (BASELINE.json configs[1])" % (wl.cfg["what"], wl.B),
                    "global_batch": global_b, "parallelism": "dp%d batch-sharded" % world,
                    "kernel_path": paths},

@@ -100,3 +100,4 @@ def test_single_rank_stub_line_has_the_contract_fields():
               "vs_baseline", "dtype", "data", "config", "roofline", "sustained_ms_per_step"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 32 and d["vs_baseline"] is None
+    assert d["data"].startswith("STUB") and d["config"]["kernel_path"] == "stub"   # can never pass for a measurement
