@@ -514,6 +514,7 @@ static int launch_bwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, con
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; }
   }
+  hp_debug_plan("hp_bwd2", hp_bwd2_kernel<ND, MOD, T, WAVES, NKS, NS>, 64 * (WAVES + NS), lds, (long)hd.ranges * g.K);
   hipLaunchKernelGGL((hp_bwd2_kernel<ND, MOD, T, WAVES, NKS, NS>), dim3(hd.ranges, g.K), dim3(64 * (WAVES + NS)), lds,
                      stream, g, hd, (const Raw *)xt, (const U4 *)wpb, btab, (const Raw *)t.grad_output,
                      (const Raw *)t.offset, (const Raw *)t.mask, (Raw *)gcol, (Raw *)t.grad_offset,

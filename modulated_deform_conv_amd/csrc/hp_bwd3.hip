@@ -411,6 +411,7 @@ static int launch_bwd3(const Geom &g, const HpDims &hd, const Tensors &t, const 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; }
   }
+  hp_debug_plan("hp_bwd3", hp_bwd3_kernel<ND, MOD, T, LPP, NKS>, 256, lds, (g.N + 127) / 128);
   hipLaunchKernelGGL((hp_bwd3_kernel<ND, MOD, T, LPP, NKS>), dim3((g.N + 127) / 128), dim3(256), lds, stream, g, hd,
                      (const Raw *)xt, (const U4 *)wpb, (const Raw *)t.grad_output, (const Raw *)t.offset,
                      (const Raw *)t.mask, (Raw *)gcol, (Raw *)colbuf, (Raw *)t.grad_offset, (Raw *)t.grad_mask, cnt);

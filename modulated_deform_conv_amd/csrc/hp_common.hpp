@@ -15,10 +15,25 @@
 //     hardware bounds check returns 0 (the reference's `if (h_low >= 0 ...)`,
 //     mdeformable_conv.cu:9-34) -- also for non-finite border pixels.
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
 #include "mdconv_common.hpp"
 #include "mfma_tile.hpp"
 
 namespace mdconv {
+
+// developer aid (MDCONV_DEBUG_PLAN=1): grid size against the resident slots of a kernel instance, once per call site
+template <typename K>
+inline void hp_debug_plan(const char *name, K kernel, int threads, size_t lds, long blocks) {
+  static const bool on = getenv("MDCONV_DEBUG_PLAN") != nullptr;
+  if (!on) return;
+  int n = 0, cus = 0, dev = 0;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(kernel), threads, lds);
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  fprintf(stderr, "[mdconv] %s: %ld workgroups of %d threads, %zu B LDS, %d resident per CU x %d CUs = %.2f rounds\n", name,
+          blocks, threads, lds, n, cus, n > 0 && cus > 0 ? (double)blocks / ((double)n * cus) : 0.0);
+}
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

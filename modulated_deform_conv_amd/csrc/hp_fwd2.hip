@@ -359,6 +359,7 @@ static int launch_fwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, con
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; } \
     }                                                                                            \
+    hp_debug_plan("hp_fwd2", hp_fwd2_kernel<ND, MOD, T, MBV, GRPV>, 256, lds, (long)grid.x * grid.y);   \
     hipLaunchKernelGGL((hp_fwd2_kernel<ND, MOD, T, MBV, GRPV>), grid, dim3(256), lds, stream, g, hd, \
                        (const Raw *)xt, (const U4 *)wpf, (const Raw *)t.bias, (const Raw *)t.offset, \
                        (const Raw *)t.mask, (Raw *)t.output, ctab);                              \

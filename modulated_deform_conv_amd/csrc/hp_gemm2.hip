@@ -199,6 +199,7 @@ int launch_gemm2(const Geom &g, const HpDims &hd, const Tensors &t, const int4 *
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; }
   }
+  hp_debug_plan("hp_gemm2", hp_gemm2_kernel<T, WAVES, MB2>, 64 * WAVES, lds, (long)hd.ranges_w * g.K);
   hipLaunchKernelGGL((hp_gemm2_kernel<T, WAVES, MB2>), dim3(hd.ranges_w * g.K), dim3(64 * WAVES), lds, stream, g, hd,
                      btab, (const Raw *)t.grad_output, (const Raw *)colbuf, part);
   return check_launch("hp_gemm2");

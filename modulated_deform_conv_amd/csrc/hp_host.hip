@@ -177,6 +177,10 @@ HpDims hp_dims(const Geom &g) {
   hd.ranges = (hd.ntiles + hd.tiles_per_range - 1) / hd.tiles_per_range;
   // GEMM-2 (dense, HBM-bound): 4 workgroups per CU in flight, at least 8 tiles per workgroup
   int rw = num_cus() * 4 / g.K;
+  {
+    static const int rw_env = getenv("MDCONV_HP_G2_SLOTS") ? atoi(getenv("MDCONV_HP_G2_SLOTS")) : 0;   // (experiments: workgroups per CU)
+    if (rw_env > 0) rw = num_cus() * rw_env / g.K;
+  }
   if (rw < 1) rw = 1;
   if (rw > hd.max_ranges) hd.max_ranges = rw;
   if (rw > (hd.ntiles + 7) / 8) rw = (hd.ntiles + 7) / 8;
