@@ -39,6 +39,37 @@ __global__ __launch_bounds__(256) void hp_nchw_to_nhwc_kernel(int C, int Cp, int
   }
 }
 
+// The same copy with 8-byte loads along q (4 pixels of one channel per lane: 4 load instructions per thread instead
+// of 16 two-byte ones) for S a multiple of 4 and an 8-byte aligned source; LDS tile and the 16-byte stores as above.
+// Picked for rows of 512 bytes (cfg3, C = 256), where the transposing-read variant below loses.
+__global__ __launch_bounds__(256) void hp_nchw_to_nhwc_q4_kernel(int C, int Cp, int S,
+                                                                 const unsigned short *__restrict__ x,
+                                                                 unsigned short *__restrict__ xt) {
+  __shared__ __attribute__((aligned(8))) unsigned short t[64][68];   // pitch 136 B: 8-byte aligned rows
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, q0 = blockIdx.x * 64;
+  const int u = threadIdx.x & 15, r0 = threadIdx.x >> 4;   // pixel quad, channel row (16 rows per pass)
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = r0 + 16 * pass, c = c0 + r, q = q0 + u * 4;
+    uint2 v = make_uint2(0u, 0u);
+    if (c < C && q < S) v = *reinterpret_cast<const uint2 *>(x + ((size_t)b * C + c) * S + q);   // S % 4 == 0: whole quad inside
+    *reinterpret_cast<uint2 *>(&t[r][u * 4]) = v;
+  }
+  __syncthreads();
+  for (int item = threadIdx.x; item < 64 * 8; item += 256) {
+    const int ql = item >> 3, oct = item & 7;
+    const int q = q0 + ql, c = c0 + oct * 8;
+    if (q < S && c < Cp) {
+      U4 v;
+      v.x = t[oct * 8 + 0][ql] | ((u32)t[oct * 8 + 1][ql] << 16);
+      v.y = t[oct * 8 + 2][ql] | ((u32)t[oct * 8 + 3][ql] << 16);
+      v.z = t[oct * 8 + 4][ql] | ((u32)t[oct * 8 + 5][ql] << 16);
+      v.w = t[oct * 8 + 6][ql] | ((u32)t[oct * 8 + 7][ql] << 16);
+      *reinterpret_cast<U4 *>(xt + ((size_t)b * S + q) * Cp + c) = v;
+    }
+  }
+}
+
 // The same copy for S a multiple of 8 (and a 16-byte aligned source): 16-byte loads along q (2 per thread instead of
 // 16 two-byte ones), rows written to LDS as loaded, and the transpose done by the LDS itself -- ds_read_b64_tr_b16
 // hands lane i of a 16-lane group column i of a 4 x 16 block, two of them are the 8 channels of one output pixel.
@@ -236,6 +267,9 @@ int hp_nchw_to_nhwc(const Geom &g, const HpDims &hd, const void *x, void *xt, hi
   static const bool vec_env = !(getenv("MDCONV_HP_NHWC_VEC") && atoi(getenv("MDCONV_HP_NHWC_VEC")) == 0);
   if (vec_env && hd.Cp <= 128 && g.S_i % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     hipLaunchKernelGGL(hp_nchw_to_nhwc_vec_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
+                       (const unsigned short *)x, (unsigned short *)xt);
+  else if (vec_env && g.S_i % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
+    hipLaunchKernelGGL(hp_nchw_to_nhwc_q4_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
                        (const unsigned short *)x, (unsigned short *)xt);
   else
     hipLaunchKernelGGL(hp_nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
