@@ -108,9 +108,13 @@ __global__ __launch_bounds__(256) void hp_nchw_to_nhwc_vec_kernel(int C, int Cp,
 // forward A operand: wpf[tap][chunk][oblk][lane][8] = W[o = oblk*32 + (lane&31)]
 //                                                      [c = chunk*16 + 8*(lane>>5) + j][tap]
 // dense block-diagonal over conv groups (0 where o and c belong to different groups, or padding).
+__device__ void hp_ctab_fill(const Geom &g, const HpDims &hd, int2 *__restrict__ ctab);
+__device__ __forceinline__ int4 hp_btab_entry(const Geom &g, int cblk);
+// (block 0 also writes the chunk table the forward kernel reads: one launch less than a table kernel of its own)
 __global__ __launch_bounds__(256) void hp_pack_fwd_kernel(Geom g, HpDims hd,
                                                           const unsigned short *__restrict__ w,
-                                                          U4 *__restrict__ wpf) {
+                                                          U4 *__restrict__ wpf, int2 *__restrict__ ctab) {
+  if (blockIdx.x == 0) hp_ctab_fill(g, hd, ctab);
   const int nchunks = hd.Cp / 16;
   const int64_t total = (int64_t)g.K * nchunks * hd.oblks * 64;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void hp_pack_fwd_kernel(Geom g, HpDims hd,
 
 // per workgroup row (`orange`) and 16-channel chunk: the range of the row's output-channel blocks
 // that can be non-zero (relative to the row's first block); entry [nchunks] = the row's chunk range
-__global__ void hp_ctab_kernel(Geom g, HpDims hd, int2 *__restrict__ ctab) {
+__device__ void hp_ctab_fill(const Geom &g, const HpDims &hd, int2 *__restrict__ ctab) {
   const int nchunks = hd.Cp / 16;
   for (int orange = threadIdx.x; orange < hd.oranges; orange += blockDim.x) {
     int2 *ct = ctab + orange * (nchunks + 1);
@@ -168,9 +172,12 @@ __host__ __device__ inline int hp_sigma(int i) { return 16 * ((i >> 2) & 1) + 4 
 
 // backward A operand (W^T): wpb[tap][cblk][ks][lane][8] = W[o = o_base(cblk) + ks*16 + 8*(lane>>5) + j]
 //                                                           [c = cblk*32 + sigma(lane&31)][tap]
-__global__ __launch_bounds__(256) void hp_pack_bwd_kernel(Geom g, HpDims hd, const int4 *__restrict__ btab,
+// (the per-block output base is computed in place; block 0 writes the table the later kernels read)
+__global__ __launch_bounds__(256) void hp_pack_bwd_kernel(Geom g, HpDims hd, int4 *__restrict__ btab,
                                                           const unsigned short *__restrict__ w,
                                                           U4 *__restrict__ wpb) {
+  if (blockIdx.x == 0)
+    for (int cb = threadIdx.x; cb < hd.cblks; cb += blockDim.x) btab[cb] = hp_btab_entry(g, cb);
   const int64_t total = (int64_t)g.K * hd.cblks * hd.nks * 64;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int64_t r = i;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void hp_pack_bwd_kernel(Geom g, HpDims hd, con
     const int cblk = (int)(r % hd.cblks);
     const int tap = (int)(r / hd.cblks);
     const int c = cblk * 32 + hp_sigma(lane & 31);
-    const int ob = btab[cblk].x + ks * 16 + 8 * (lane >> 5);
+    const int ob = hp_btab_entry(g, cblk).x + ks * 16 + 8 * (lane >> 5);
     unsigned short e[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -195,13 +202,11 @@ __global__ __launch_bounds__(256) void hp_pack_bwd_kernel(Geom g, HpDims hd, con
 }
 
 // per 32-channel block: first output channel (32-aligned) of the groups its channels belong to
-__global__ void hp_btab_kernel(Geom g, HpDims hd, int4 *__restrict__ btab) {
-  for (int cblk = threadIdx.x; cblk < hd.cblks; cblk += blockDim.x) {
-    const int c_lo = min(cblk * 32, g.C - 1), c_hi = min(cblk * 32 + 31, g.C - 1);
-    const int o_lo = (c_lo / g.Cg) * g.Og, o_hi = (c_hi / g.Cg + 1) * g.Og;
-    const int base = o_lo / 32 * 32;
-    btab[cblk] = make_int4(base, (o_hi - base + 31) / 32, 0, 0);
-  }
+__device__ __forceinline__ int4 hp_btab_entry(const Geom &g, int cblk) {
+  const int c_lo = min(cblk * 32, g.C - 1), c_hi = min(cblk * 32 + 31, g.C - 1);
+  const int o_lo = (c_lo / g.Cg) * g.Og, o_hi = (c_hi / g.Cg + 1) * g.Og;
+  const int base = o_lo / 32 * 32;
+  return make_int4(base, (o_hi - base + 31) / 32, 0, 0);
 }
 
 // grad_weight[o][c][tap] (+)= sum over the pixel ranges of part[tap][range][cblk][ob][lane][16]
@@ -225,8 +230,14 @@ __global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, in
       const int64_t per_range = (int64_t)hd.cblks * hd.MB2 * 1024;
       const float *p = part + ((int64_t)tap * ranges) * per_range + ((int64_t)cblk * hd.MB2 + ob) * 1024 +
                        lane * 16 + reg;
-      float s = 0.f;
-      for (int k = 0; k < ranges; ++k) s += p[(int64_t)k * per_range];
+      float s = 0.f;   // four partials in flight, fixed order (a plain loop left one dependent load per range)
+      int k = 0;
+      for (; k + 4 <= ranges; k += 4) {
+        const float a0 = p[(int64_t)k * per_range], a1 = p[(int64_t)(k + 1) * per_range];
+        const float a2 = p[(int64_t)(k + 2) * per_range], a3 = p[(int64_t)(k + 3) * per_range];
+        s += (a0 + a1) + (a2 + a3);
+      }
+      for (; k < ranges; ++k) s += p[(int64_t)k * per_range];
       const int64_t e = ((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap;
       // calls cut into batch chunks keep the running sum in fp32 (gw32) and round ONCE, after the
       // last chunk, like the single-chunk path
@@ -281,18 +292,12 @@ int hp_pack_fwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *
                         int2 *ctab, hipStream_t stream) {
   const int64_t total = (int64_t)g.K * (hd.Cp / 16) * hd.oblks * 64;
   hipLaunchKernelGGL(hp_pack_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, hd,
-                     (const unsigned short *)w, (U4 *)wpf);
-  int rc = check_launch("hp_pack_fwd");
-  if (rc) return rc;
-  hipLaunchKernelGGL(hp_ctab_kernel, dim3(1), dim3(64), 0, stream, g, hd, ctab);
-  return check_launch("hp_ctab");
+                     (const unsigned short *)w, (U4 *)wpf, ctab);
+  return check_launch("hp_pack_fwd");
 }
 
 int hp_pack_bwd_weights(const Geom &g, const HpDims &hd, int dtype, const void *w, void *wpb,
                         int4 *btab, hipStream_t stream) {
-  hipLaunchKernelGGL(hp_btab_kernel, dim3(1), dim3(64), 0, stream, g, hd, btab);
-  int rc = check_launch("hp_btab");
-  if (rc) return rc;
   const int64_t total = (int64_t)g.K * hd.cblks * hd.nks * 64;
   hipLaunchKernelGGL(hp_pack_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, hd, btab,
                      (const unsigned short *)w, (U4 *)wpb);
