@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void hp_csr_scan_kernel(int S, const int *__re
   if (hi == S && threadIdx.x == 0) rp[S] = carry;
 }
 
-// entry = 2 x int4: (src, wx, wy, rl0), (rh0, rl1, rh1, anchor)
+// 3-D entry = 2 x int4: (src, wx, wy, rl0), (rh0, rl1, rh1, anchor).
+// 2-D entry = 1 x int4 (round 4: half the list bytes; cfg3 writes 3.6 M of them): (src, (rh0 wx, rh0 wy), (rl0 wx,
+// rl0 wy), anchor) -- the four weight products the gathers use, as two packed fp16 pairs.  Their 11 significant bits
+// match what the 16-bit grad_col rows they multiply carry.
 template <int ND, bool MOD, typename T>
 __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
                                                           const typename T::Raw *__restrict__ offset,
@@ -99,10 +102,15 @@ __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
     if (sa.on) {
       // the counters double as cursors, counted down: no clearing pass between scan and fill
       const int pos = rowptr[(int64_t)seg * (S_e + 1) + sa.qa] + atomicSub(cursor + (int64_t)seg * S_e + sa.qa, 1) - 1;
-      int4 *e = entries + ((int64_t)seg * ((int64_t)g.K * g.S_o) + pos) * 2;
-      e[0] = make_int4(tap * g.S_o + pix, __float_as_int(sa.wx), __float_as_int(sa.wy), __float_as_int(sa.rl[0]));
-      e[1] = make_int4(__float_as_int(sa.rh[0]), __float_as_int(ND == 3 ? sa.rl[ND - 2] : 0.f),
-                       __float_as_int(ND == 3 ? sa.rh[ND - 2] : 0.f), sa.qa);
+      if constexpr (ND == 2) {
+        entries[(int64_t)seg * ((int64_t)g.K * g.S_o) + pos] =
+            make_int4(tap * g.S_o + pix, (int)F16::pack(sa.rh[0] * sa.wx, sa.rh[0] * sa.wy),
+                      (int)F16::pack(sa.rl[0] * sa.wx, sa.rl[0] * sa.wy), sa.qa);
+      } else {
+        int4 *e = entries + ((int64_t)seg * ((int64_t)g.K * g.S_o) + pos) * 2;
+        e[0] = make_int4(tap * g.S_o + pix, __float_as_int(sa.wx), __float_as_int(sa.wy), __float_as_int(sa.rl[0]));
+        e[1] = make_int4(__float_as_int(sa.rh[0]), __float_as_int(sa.rl[ND - 2]), __float_as_int(sa.rh[ND - 2]), sa.qa);
+      }
     }
   }
 }
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
     const bool chan_on = c8 < c_end;
     const int seg = b * g.DG + dg;
     const int *rp = rowptr + (int64_t)seg * (S_e + 1);
-    const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * 2;
+    const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * (ND == 2 ? 1 : 2);
     const int c_voff = chan_on ? c8 * 2 : kHpOob;
     // coordinates of the target of the current step (first step: qs - 1, the carry-in column)
     int tc[ND];
@@ -176,13 +184,21 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
           int src_m = 0;
           float fx_m = 0.f, fy_m = 0.f;   // weights 0, row 0 beyond the list
           if (r < cnt) {
-            const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
             // target = low + 1 - s_a on axis a: s_a = 1 -> the low side (rl), 0 -> the high side (rh)
-            float rw = ((s >> (L - 1)) & 1) ? __int_as_float(ea4.w) : __int_as_float(eb4.x);
-            if (ND == 3) rw *= (s & 1) ? __int_as_float(eb4.y) : __int_as_float(eb4.z);
-            src_m = ea4.x;
-            fx_m = rw * __int_as_float(ea4.y);
-            fy_m = rw * __int_as_float(ea4.z);
+            if constexpr (ND == 2) {
+              const int4 e4 = ent[base + r];
+              const u32 pr = (u32)(s ? e4.z : e4.y);
+              src_m = e4.x;
+              fx_m = F16::lo(pr);
+              fy_m = F16::hi(pr);
+            } else {
+              const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
+              float rw = ((s >> (L - 1)) & 1) ? __int_as_float(ea4.w) : __int_as_float(eb4.x);
+              rw *= (s & 1) ? __int_as_float(eb4.y) : __int_as_float(eb4.z);
+              src_m = ea4.x;
+              fx_m = rw * __int_as_float(ea4.y);
+              fy_m = rw * __int_as_float(ea4.z);
+            }
           }
 #pragma unroll
           for (int u0 = 0; u0 < LPD; u0 += UB) {
@@ -278,7 +294,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   const int a_last = run_on ? min(a_lo + kRunA, S_e) - 1 : -1;  // last one
   const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * hd.Cp, (size_t)g.K * g.S_o * hd.Cp * 2);
   const int *rp = rowptr + (int64_t)seg * (S_e + 1);
-  const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * 2;
+  const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * (ND == 2 ? 1 : 2);
   const bool chan_on = r * 8 < cseg;
   const int c_voff = chan_on ? (dg * cseg + r * 8) * 2 : kHpOob;
   Sum *out = sums + ((int64_t)seg * S_e * NS) * cseg + r * 8;
@@ -316,21 +332,29 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   };
   while (__any(e_pos < e_end)) {
     // this lane's entry of the batch
+    // this lane's entry: row, anchor and the weight of the row towards (target row s, column x / x + 1)
     int src_m = 0, anc_m = 0x7fffffff;
-    float wx_m = 0.f, wy_m = 0.f, fa_m[NS];
+    float px_m[NS], py_m[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) fa_m[s] = 0.f;
+    for (int s = 0; s < NS; ++s) px_m[s] = py_m[s] = 0.f;
     if (e_pos + r < e_end) {
-      const int4 ea4 = ent[(int64_t)(e_pos + r) * 2], eb4 = ent[(int64_t)(e_pos + r) * 2 + 1];
-      src_m = ea4.x;
-      wx_m = __int_as_float(ea4.y); wy_m = __int_as_float(ea4.z);
-      const float f0l = __int_as_float(ea4.w), f0h = __int_as_float(eb4.x);
-      if constexpr (ND == 2) { fa_m[0] = f0h; fa_m[1] = f0l; }
-      else {
+      if constexpr (ND == 2) {
+        const int4 e4 = ent[e_pos + r];
+        src_m = e4.x;
+        px_m[0] = F16::lo((u32)e4.y); py_m[0] = F16::hi((u32)e4.y);
+        px_m[1] = F16::lo((u32)e4.z); py_m[1] = F16::hi((u32)e4.z);
+        anc_m = e4.w;
+      } else {
+        const int4 ea4 = ent[(int64_t)(e_pos + r) * 2], eb4 = ent[(int64_t)(e_pos + r) * 2 + 1];
+        src_m = ea4.x;
+        const float wx = __int_as_float(ea4.y), wy = __int_as_float(ea4.z);
+        const float f0l = __int_as_float(ea4.w), f0h = __int_as_float(eb4.x);
         const float f1l = __int_as_float(eb4.y), f1h = __int_as_float(eb4.z);
-        fa_m[0] = f0h * f1h; fa_m[1] = f0h * f1l; fa_m[2] = f0l * f1h; fa_m[3] = f0l * f1l;
+        const float fa[4] = {f0h * f1h, f0h * f1l, f0l * f1h, f0l * f1l};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { px_m[s] = fa[s] * wx; py_m[s] = fa[s] * wy; }
+        anc_m = eb4.w;
       }
-      anc_m = eb4.w;
     }
     const int cnt = max(0, min(LPD, e_end - e_pos));
     U4 va[UB], vb[UB];
@@ -345,16 +369,15 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
 #pragma unroll
       for (int k = 0; k < UB; ++k) {
         const int anc = __shfl(anc_m, u0 + k, LPD);
-        const float wx = __shfl(wx_m, u0 + k, LPD), wy = __shfl(wy_m, u0 + k, LPD);
-        float fa[NS];
+        float px[NS], py[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) fa[s] = __shfl(fa_m[s], u0 + k, LPD);
+        for (int s = 0; s < NS; ++s) { px[s] = __shfl(px_m[s], u0 + k, LPD); py[s] = __shfl(py_m[s], u0 + k, LPD); }
         if (u0 + k < cnt) {
           while (cur_a < anc) flush();
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
-            mac8<T>(cur[s], v[k], fa[s] * wx);
-            mac8<T>(nxt[s], v[k], fa[s] * wy);
+            mac8<T>(cur[s], v[k], px[s]);
+            mac8<T>(nxt[s], v[k], py[s]);
           }
         }
       }
