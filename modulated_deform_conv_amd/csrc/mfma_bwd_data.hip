@@ -476,7 +476,11 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
           const int o = st[c] + 16 * gl_j;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
+#ifdef ABL_B1_NOGATHER   // developer ablation (timing only): no corner loads in the channels-last drain
+            const float4 x = make_float4((float)o, 1.f, 2.f, 3.f);
+#else
             const float4 x = buf_load4(r_in, o + 64 * k, cbase_p * 4);
+#endif
             float *d = v.f + (c * 4 + k) * 4;
             d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
           }
@@ -518,7 +522,11 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         gc[k] = *reinterpret_cast<const float4 *>(Pk + pxl * 64 + 4 * ((4 * k + gl_j) ^ swz));
+#ifdef ABL_B1_NOSTORE   // developer ablation (timing only): grad_col rows are (practically) never written
+      if (cp == 0 && gc[0].x == 1.2345e30f) {
+#else
       if (cp == 0) {   // grad_col row: the quad stores 64 contiguous bytes per instruction
+#endif
         const int gv = st[NC] + 16 * gl_j;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -649,7 +657,11 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       for (int a = 0; a < ND; ++a) rp[a * BNP] = goff[a];
       rp[ND * BNP] = gm;
     }
+#ifdef ABL_B1_NOFLUSH   // developer ablation (timing only): no workgroup-wide flush of the grad_offset / grad_mask partials
+    if (false) {
+#else
     if (flush_ok && (slot == kTapGroup - 1 || tapp == g.K - 1 || last)) {
+#endif
       __syncthreads();
       // single owner of every (b, dg, tap, pix): plain read-modify-write (or write, mdconv_set_accumulate)
       const int tap0 = tapp - slot;
