@@ -293,8 +293,10 @@ bool bwd_channels_last(const Geom &g) {
   // cfg2 (random offsets put every lane in its own sector; the three GEMMs keep the L1 70-75 %
   // busy), the channels-last ones 16 per KiB -- with the line-wide drain of GEMM-1 and the XCD-aware
   // unit order of GEMM-2 the backward is 4-25 % faster over the 2-D shapes of tools/cl_sweep.py
-  // (cfg2 2.85 -> 2.75 ms) once the layout pass is amortised: from ~16 k output pixels up.
-  return g.nd == 3 || g.G >= 8 || g.N >= 16384;
+  // (cfg2 2.85 -> 2.75 ms) once the layout pass is amortised.  Round 4, with GEMM-2's split-K sized to the resident
+  // slots: equal at 6 k output pixels, 1-10 % faster from 9 k up (tools/cl_sweep_small.py: B = 2 ... 16 shards of
+  // 64 / 128 / 256 channels), so the threshold moved from 16 k to 8 k pixels -- the B = 4 shard of cfg2 included.
+  return g.nd == 3 || g.G >= 8 || g.N >= 8192;
 }
 
 int nchw_to_nhwc_f32(const Geom &g, const float *x, float *xt, hipStream_t stream) {

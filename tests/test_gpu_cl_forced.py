@@ -1,5 +1,5 @@
 """The channels-last variants of the fp32 kernels -- forward, GEMM-2 and the line-wide GEMM-1 drain
-(with its 3-tap flush groups) -- are selected by shape (3-D always, 2-D from ~16 k output pixels), so
+(with its 3-tap flush groups) -- are selected by shape (3-D always, 2-D from ~8 k output pixels), so
 the small 2-D parity cases never reach them on their own.  The selection knobs are read once per
 process, hence a child process: the MFMA-eligible parity cases run again with all three forced on
 and are compared with the oracle as usual (tests/test_gpu_parity.py)."""

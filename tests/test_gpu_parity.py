@@ -232,7 +232,7 @@ def test_fp32_non_finite_border_pixel_is_not_read(path):
 def _inf_case(name):
     from tests.cases import D2, D3, M2, _c
     return {
-        # channels-last backward (3-D always; 2-D from 16 k output pixels): every gather addresses corners one by one
+        # channels-last backward (3-D always; 2-D from 8 k output pixels): every gather addresses corners one by one
         "dcn3d_c64_cl": _c("inf_dcn3d_c64", D3, 1, 64, 32, (5, 6, 5), 3, seed=161),
         "mdcn2d_c64_cl": _c("inf_mdcn2d_c64", M2, 6, 64, 32, (56, 56), 3, seed=162),
         # small 2-D shape: the NCHW backward kernels (8-byte pair loads in GEMM-1's drain and in GEMM-2)
@@ -243,7 +243,7 @@ def _inf_case(name):
 @pytest.mark.parametrize("name,path", [
     ("dcn3d_c64_cl", "mfma"), ("mdcn2d_c64_cl", "mfma"), ("mdcn2d_c64_small", "direct"),
     pytest.param("mdcn2d_c64_small", "mfma", marks=pytest.mark.xfail(
-        strict=True, reason="documented deviation (INTEGRATION.md, Limits): below 16 k output pixels the fp32 2-D "
+        strict=True, reason="documented deviation (INTEGRATION.md, Limits): below 8 k output pixels the fp32 2-D "
         "backward keeps the NCHW kernels, whose 8-byte pair loads give the neighbour of an out-of-image corner the "
         "weight 0 (0 * Inf = NaN) in GEMM-1's drain and in GEMM-2; the forward and every channels-last backward "
         "never read it"))])
