@@ -37,8 +37,10 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-# mfma_bwd_data.hip: SLP vectorisation turns the drain's independent fp32 chains into v_pk_fma_f32 /
-# v_pk_add_f32 (10-24 cycles each on gfx950, tools/ubench_valu.hip) and blocks the DPP-operand fusion
+# mfma_bwd_data.hip: without SLP vectorisation.  Packed fp32 math is no faster beside MFMAs (v_pk_fma_f32 issues at
+# 1.35-1.45x the v_fma_f32 time for twice the work, tools/ubench_pkfma.hip; GEMM-1 measures the same with the
+# vectoriser on or off), and the vectoriser's register pairs keep hipcc from fusing the DPP
+# operands of the drain's quad sums; the flag keeps that instance scratch-free at 253-256 VGPRs.
 FILE_FLAGS = {"mfma_bwd_data.hip": ["-fno-slp-vectorize"]}
 
 

@@ -73,8 +73,9 @@ __global__ __launch_bounds__(256) void hp_csr_scan_kernel(int S, const int *__re
 
 // 3-D entry = 2 x int4: (src, wx, wy, rl0), (rh0, rl1, rh1, anchor).
 // 2-D entry = 1 x int4 (round 4: half the list bytes; cfg3 writes 3.6 M of them): (src, (rh0 wx, rh0 wy), (rl0 wx,
-// rl0 wy), anchor) -- the four weight products the gathers use, as two packed fp16 pairs.  Their 11 significant bits
-// match what the 16-bit grad_col rows they multiply carry.
+// rl0 wy), anchor) -- the four weight products the gathers use (mask folded in), as two packed pairs in the TENSORS'
+// 16-bit type: as many significant bits as the grad_col rows they multiply carry, and the range of the mask tensor
+// itself (a bf16 mask above 65504 or a product below 6e-8 would be lost in fp16 pairs -- advisor, round 4).
 template <int ND, bool MOD, typename T>
 __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
                                                           const typename T::Raw *__restrict__ offset,
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
       const int pos = rowptr[(int64_t)seg * (S_e + 1) + sa.qa] + atomicSub(cursor + (int64_t)seg * S_e + sa.qa, 1) - 1;
       if constexpr (ND == 2) {
         entries[(int64_t)seg * ((int64_t)g.K * g.S_o) + pos] =
-            make_int4(tap * g.S_o + pix, (int)F16::pack(sa.rh[0] * sa.wx, sa.rh[0] * sa.wy),
-                      (int)F16::pack(sa.rl[0] * sa.wx, sa.rl[0] * sa.wy), sa.qa);
+            make_int4(tap * g.S_o + pix, (int)T::pack(sa.rh[0] * sa.wx, sa.rh[0] * sa.wy),
+                      (int)T::pack(sa.rl[0] * sa.wx, sa.rl[0] * sa.wy), sa.qa);
       } else {
         int4 *e = entries + ((int64_t)seg * ((int64_t)g.K * g.S_o) + pos) * 2;
         e[0] = make_int4(tap * g.S_o + pix, __float_as_int(sa.wx), __float_as_int(sa.wy), __float_as_int(sa.rl[0]));
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
               const int4 e4 = ent[base + r];
               const u32 pr = (u32)(s ? e4.z : e4.y);
               src_m = e4.x;
-              fx_m = F16::lo(pr);
-              fy_m = F16::hi(pr);
+              fx_m = T::lo(pr);
+              fy_m = T::hi(pr);
             } else {
               const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
               float rw = ((s >> (L - 1)) & 1) ? __int_as_float(ea4.w) : __int_as_float(eb4.x);
@@ -341,8 +342,8 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
       if constexpr (ND == 2) {
         const int4 e4 = ent[e_pos + r];
         src_m = e4.x;
-        px_m[0] = F16::lo((u32)e4.y); py_m[0] = F16::hi((u32)e4.y);
-        px_m[1] = F16::lo((u32)e4.z); py_m[1] = F16::hi((u32)e4.z);
+        px_m[0] = T::lo((u32)e4.y); py_m[0] = T::hi((u32)e4.y);
+        px_m[1] = T::lo((u32)e4.z); py_m[1] = T::hi((u32)e4.z);
         anc_m = e4.w;
       } else {
         const int4 ea4 = ent[(int64_t)(e_pos + r) * 2], eb4 = ent[(int64_t)(e_pos + r) * 2 + 1];

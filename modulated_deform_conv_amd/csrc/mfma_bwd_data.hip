@@ -117,11 +117,7 @@ __device__ unsigned long long g_b1_timing[12];
 #ifndef B1_MINWAVES
 #define B1_MINWAVES 2
 #endif
-// PURE: GEMM-1 and the grad_col stream only (+ packed grad_out and grad_bias partials): the corner sums, tap table
-// and counting live in mfma_coord.hip (coord_grad_kernel / tap_prepass_kernel), which run BESIDE the two GEMMs
-// instead of inside this one (round 4: the fused drain kept this kernel at 0.69 of the matrix peak with 253
-// registers; without it the same loop measures 0.88-0.92 ms at cfg2 against 1.08).
-template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL, bool PURE = false>
+template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL>
 __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
@@ -341,6 +337,14 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
   float w[NC], dw[ND][NC], mg = 0.f;
   float S[NC];
   float delta_n[ND], m_n = 1.f;   // raw offset / mask of the unit whose K loop is running
+  // NCHW drain: elements of the corner pairs that come along with a wanted neighbour but that the reference never reads
+  // (the sample sits across the first / last column, mdeformable_conv.cu:256-267).  Their weight is 0, but 0 * Inf = NaN:
+  // the waves that hold such a lane select them away in `consume` (lane masks in SGPRs, wave-uniform branch), as the
+  // forward does (mfma_fwd.hip); pairs with nothing to read are parked out of the buffer's range.
+  typedef unsigned long long lanemask_t;
+  lanemask_t bad[NC];
+#pragma unroll
+  for (int ci = 0; ci < NC; ++ci) bad[ci] = 0ull;
   f32x16 acc[MB], accp[MB];
 #pragma unroll
   for (int pi = 0; pi < NP; ++pi) voff[pi] = kOob;
@@ -364,10 +368,6 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
   // inverted scatter map (first pass of the CSR build, csr_pass_kernel<.., false> otherwise):
   // fire-and-forget integer atomics that disappear under the MFMAs.
   auto new_tap_state = [&](int tapp, int dgp, bool count) {
-    if constexpr (PURE) {
-      gc_voff = pp.live ? ((((pp.b * g.K + tapp) * g.S_o + pp.pix) * g.C) + 4 * kh) * 4 : kOob;
-      return;
-    }
     int tcd[ND];
     tap_coords<ND>(g, tapp, tcd);
     TapCoef<ND, float> tc;
@@ -409,7 +409,11 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
             ev[2 * pi] = pp.live && prx[pi] ? (pp.b * g.S_i + pidx[pi]) * g.C * 4 : kOob;
             ev[2 * pi + 1] = pp.live && pry[pi] ? (pp.b * g.S_i + pidx[pi] + 1) * g.C * 4 : kOob;
           } else {
-            ev[pi] = pp.live ? (pp.b * g.C * g.S_i + pidx[pi]) * 4 : 0;
+            // NCHW GEMM-2: byte offset of the pair (4-byte aligned), bit 0 / 1 set = first / second element is loaded
+            // but not to be used (mfma_bwd_weight.hip selects it away); nothing to read: parked out of range
+            ev[pi] = !pp.live ? 0
+                     : ((prx[pi] || pry[pi]) ? ((pp.b * g.C * g.S_i + pidx[pi]) * 4) | (pry[pi] && !prx[pi] ? 1 : 0) | (prx[pi] && !pry[pi] ? 2 : 0)
+                                             : kOob);
             ev[NP + pi] = 0;
           }
           ev[NC + 2 * pi] = pp.live ? __float_as_int(px[pi] * m_n) : 0;
@@ -422,7 +426,11 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     }
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
-      voff[pi] = (pp.b * g.C * g.S_i + pidx[pi] + 4 * kh * g.S_i) * 4;
+      voff[pi] = (prx[pi] || pry[pi]) ? (pp.b * g.C * g.S_i + pidx[pi] + 4 * kh * g.S_i) * 4 : kOob;
+      if (!CL) {
+        bad[2 * pi] = __ballot(pry[pi] && !prx[pi]);
+        bad[2 * pi + 1] = __ballot(prx[pi] && !pry[pi]);
+      }
       voffc[2 * pi] = prx[pi] ? (pp.b * g.S_i + pidx[pi]) * g.C * 4 + 16 * kh : kOob;
       voffc[2 * pi + 1] = pry[pi] ? (pp.b * g.S_i + pidx[pi] + 1) * g.C * 4 + 16 * kh : kOob;
       w[2 * pi] = px[pi];
@@ -458,7 +466,6 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
   // row); channels-last: [quad of 4 rows][corner] float4 (one 16-byte load per corner and quad).
   struct Batch { float f[RB * NC]; };
   auto gather = [&](int q, int cbase_p, Batch &v) {
-    if constexpr (PURE) return;
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
     if (CL) {
       // Line-wide gathers: batch q covers one half of the wave's 32 pixels (16, all 64 channels) and
@@ -568,16 +575,31 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       buf_store4(r_gc, vo, cu4 * 4, accp[mb][r0 + 4 * gq], accp[mb][r0 + 4 * gq + 1],
                  accp[mb][r0 + 4 * gq + 2], accp[mb][r0 + 4 * gq + 3]);
     }
-    if constexpr (PURE) return;
     // padded channels have grad_col == 0 exactly (zero weight rows), no predicate needed
+    lanemask_t any_bad = 0ull;
 #pragma unroll
-    for (int rr = 0; rr < RB; ++rr) {
-      const float gc = accp[mb][r0 + rr];
+    for (int ci = 0; ci < NC; ++ci) any_bad |= bad[ci];
+    if (any_bad != 0ull) {   // wave-uniform: some lane holds a pair with an element the reference does not read
 #pragma unroll
-      for (int ci = 0; ci < NC; ++ci) {
-        // element ci of the corner pairs = corner ci (pair ci/2, first / second element)
-        const float x = v.f[(rr * NP + (ci >> 1)) * 2 + (ci & 1)];
-        S[ci] = fmaf(gc, x, S[ci]);
+      for (int rr = 0; rr < RB; ++rr) {
+        const float gc = accp[mb][r0 + rr];
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+          float x;
+          asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(x) : "v"(v.f[(rr * NP + (ci >> 1)) * 2 + (ci & 1)]), "s"(bad[ci]));
+          S[ci] = fmaf(gc, x, S[ci]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const float gc = accp[mb][r0 + rr];
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+          // element ci of the corner pairs = corner ci (pair ci/2, first / second element)
+          const float x = v.f[(rr * NP + (ci >> 1)) * 2 + (ci & 1)];
+          S[ci] = fmaf(gc, x, S[ci]);
+        }
       }
     }
 #pragma unroll
@@ -616,7 +638,6 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
   // LDS; `flush` (end of a tap group / of the tile / of the unit range) writes the group out ----
   int grp_lo = (u0 % g.K) % kTapGroup;   // first slot of the current tap group held in `red`
   auto finish_tap = [&](int tapp, int blk, bool flush_ok, bool last) {
-    if constexpr (PURE) return;
     float goff[ND], gm = 0.f;
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) gm = fmaf(w[ci], S[ci], gm);
@@ -749,7 +770,7 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       B1_T(11);  // ga emission, grad_bias partials
     }
     B1_T(1);
-    if (!PURE && (pass == 0 || per_block)) {
+    if (pass == 0 || per_block) {
       const int dg = per_block ? min((pass * WAVES_C + wc) * 64, g.C - 1) / g.Cdg : 0;
       const int64_t seg = (int64_t)pc.b * g.DG + dg;
       const int64_t ob = (seg * (ND * g.K) + ND * tap) * g.S_o + pc.pix;
@@ -1249,26 +1270,30 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
                       const float *xt, hipStream_t stream) {
   // cnt: per-(image, deformable group, input pixel) counters (zeroed by csr_zero_f32), counted
   // by GEMM-1 (CSR pass 1)
-#define LAUNCH_BD_(ND, MOD, WC, QPQ, CL, PURE)                                                      \
+#define LAUNCH_BD_(ND, MOD, WC, QPQ, CL)                                                            \
   do {                                                                                          \
     const int bnp = 32 * (4 / WC);                                                              \
     const int ntiles = (g.N + bnp - 1) / bnp;                                                   \
     const size_t lds = bwd_data_lds_bytes(g, bd);                                               \
     if (lds > 64 * 1024) {                                                                      \
-      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, PURE>, \
+      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; } \
     }                                                                                           \
     /* complete dispatch rounds of one-tile workgroups (2 per CU by registers, fewer by LDS),  */ \
     /* then the units of the leftover tiles spread over one more, shorter, round              */ \
     static const int percu_env = getenv("MDCONV_BD_PERCU") ? atoi(getenv("MDCONV_BD_PERCU")) : 0; \
-    static int occ_q = 0;   /* resident workgroups per CU of this instance at this LDS size */   \
-    if (occ_q == 0) {                                                                           \
+    /* resident workgroups per CU of this instance at THIS dynamic LDS size (it varies with C_out and K for  */ \
+    /* one instance: re-queried when the size changes -- advisor, round 4)                                      */ \
+    static int occ_q = 0;                                                                       \
+    static size_t occ_lds = 0;                                                                  \
+    if (occ_q == 0 || occ_lds != lds) {   /* (unsynchronised: a race only mis-sizes one launch's rounds) */ \
       int nq = 0;                                                                               \
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                       \
-          &nq, (const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, PURE>, 256, lds);       \
+          &nq, (const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, 256, lds);       \
       (void)hipGetLastError();                                                                  \
       occ_q = nq > 0 ? nq : (lds * 2 <= 160 * 1024 ? 2 : 1);                                    \
+      occ_lds = lds;                                                                            \
     }                                                                                           \
     const int per_cu = percu_env > 0 ? percu_env : occ_q;                                       \
     const int slots = num_cus() * per_cu;                                                       \
@@ -1276,7 +1301,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
     const int tpw = tpw_env > 0 ? tpw_env : 1;   /* whole tiles per workgroup of the full rounds */ \
     const int n_full = ntiles / (slots * tpw) * slots;                                          \
     const int n_tail = (int)std::min<int64_t>((int64_t)(ntiles - n_full * tpw) * g.K, slots);   \
-    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, PURE>), dim3(n_full + n_tail), \
+    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>), dim3(n_full + n_tail), \
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
@@ -1286,9 +1311,8 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
 /* channels-last drain only where it pays (3-D) */                                                \
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
   do {                                                                                          \
-    if (bd.split_drain) LAUNCH_BD_(ND, false, WC, QPQ, false, true);                            \
-    else if (xt != nullptr && bd.cl_drain) LAUNCH_BD_(ND, MOD, WC, QPQ, true, false);           \
-    else LAUNCH_BD_(ND, MOD, WC, QPQ, false, false);                                            \
+    if (xt != nullptr && bd.cl_drain) LAUNCH_BD_(ND, MOD, WC, QPQ, true);                       \
+    else LAUNCH_BD_(ND, MOD, WC, QPQ, false);                                                   \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \

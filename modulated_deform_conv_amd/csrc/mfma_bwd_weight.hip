@@ -104,6 +104,9 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // vo: byte offsets of the corner pairs; their two low bits flag an element that comes along with the 8-byte load
+  // but that the reference never reads (bit 0: the first, bit 1: the second; written by GEMM-1) -- its weight is 0,
+  // and it must not be multiplied at all (0 * Inf = NaN): `commit` selects it away behind a wave-uniform branch
   struct Tab { int vo[NP]; float w[NC]; };
   auto load_tab = [&](Tab &tb, int t) {
     const int soff = t * 16 * entry_bytes;
@@ -127,12 +130,24 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   auto gather = [&](const Tab &tb) {
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
-      const int vo = tb.vo[pi] + chan_voff;
+      const int vo = (tb.vo[pi] & ~3) + chan_voff;
 #pragma unroll
       for (int i = 0; i < CT; ++i) rg[i][pi] = buf_load2(r_in, vo, i * chan_soff);
     }
   };
   auto commit = [&](const Tab &tb, int t, float *Bb) {
+    int flags = 0;
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) flags |= tb.vo[pi];
+    if (__any((flags & 3) != 0)) {   // wave-uniform
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          rg[i][pi].x = (tb.vo[pi] & 1) ? 0.f : rg[i][pi].x;
+          rg[i][pi].y = (tb.vo[pi] & 2) ? 0.f : rg[i][pi].y;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
       float val = tb.w[0] * rg[i][0].x;
@@ -299,12 +314,12 @@ int mfma_bwd_weight_occupancy(int nd, bool padn, int wtile) {
 
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, const float *xt,
-                        hipStream_t stream, const float *gcol, float *sbuf) {
+                        hipStream_t stream) {
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
   const bool padn = bd.Np != g.N;
   profile_mark(2, true, stream, bd.cl ? "mfma_bwd_weight_cl_kernel" : "mfma_bwd_weight_kernel");
   if (bd.cl) {
-    const int rcl = mfma_bwd_weight_cl_launch(g, bd, xt, ga, table, part, gcol, sbuf, stream);
+    const int rcl = mfma_bwd_weight_cl_launch(g, bd, xt, ga, table, part, stream);
     if (rcl) return rcl;
   } else {
 #define LAUNCH_BW(ND, PADN, WR, WC, MB)                                                         \

@@ -31,23 +31,13 @@ __device__ unsigned long long g_b2_timing[8];
 //   <2, 2, 1, 1>   64 x 64    C_out <= 64
 //   <2, 2, 2, 1>  128 x 64    C_out <= 128
 //   <4, 1, 2, 2>  256 x 64
-//   <4, 1, 2, 4>  256 x 128  (MDCONV_BW_WIDE=1)
-// COORD (round 4, 2-D): the kernel also produces the corner sums of the coordinate gradients.  A thread of the
-// column-slab generation holds the 2^ND corner values of (pixel, 4 channels) anyway; with the matching 16-byte
-// piece of the grad_col row it forms  S[ci] = sum_c grad_col[c] * corner[ci][c]  over its 4 channels, the 16
-// lanes of a pixel (one DPP row) reduce it, and lane 0 stores the 64-channel partial to
-// sbuf[cblk][tap][n][ci]; coord_finish_kernel (mfma_coord.hip) adds the blocks of a deformable group and
-// applies the weights.  That takes the drain out of GEMM-1 (mfma_bwd_data.hip, PURE) without a second gather
-// pass over xt: cfg2 GEMM-1 1.09 -> 0.89 ms for +16 FMAs and +16 DPP adds per thread and chunk here.
-template <int ND, bool PADN, int WR, int WC, int MB, int NBW, bool COORD = false>
-__global__ __launch_bounds__(256, NBW == 4 ? 2 : 1) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims bd,
+template <int ND, bool PADN, int WR, int WC, int MB, int NBW>
+__global__ __launch_bounds__(256, 1) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims bd,
                                                                  const float *__restrict__ xt,
                                                                  const float *__restrict__ ga,
                                                                  const int *__restrict__ table,
-                                                                 float *__restrict__ part,
-                                                                 const float *__restrict__ gcol,
-                                                                 float *__restrict__ sbuf) {
-  static_assert(WR * WC == 4 && (WC * NBW * 32 == 64 || WC * NBW * 32 == 128), "four waves, 64 or 128 input channels");
+                                                                 float *__restrict__ part) {
+  static_assert(WR * WC == 4 && WC * NBW * 32 == 64, "four waves, 64 input channels");
   constexpr int NC = 1 << ND;
   constexpr int BK = kBK;
   constexpr int RM = WR * MB * 32, CN = WC * NBW * 32;
@@ -99,19 +89,6 @@ __global__ __launch_bounds__(256, NBW == 4 ? 2 : 1) void mfma_bwd_weight_cl_kern
   }
   const int t_voff = kk * entry_bytes;
   const int c_voff = (min(c0, g.C - CN) + cq * 4) * 4;   // C is a multiple of the tile width
-  // COORD: the grad_col row [b][tap][pix][C] of this thread's pixel, tracked incrementally (16 pixels per chunk);
-  // only the workgroups of the first row tile produce the sums (the others would repeat them)
-  static_assert(!COORD || NH == 1, "corner sums: 64-channel tiles only");
-  const bool do_coord = COORD && mtile == 0;
-  const rsrc_t r_gc = make_rsrc(COORD ? gcol : xt, COORD ? (size_t)g.B * g.K * g.S_o * g.C * sizeof(float) : 0);
-  int gq_b = 0, gq_pix = 0;
-  if (COORD) {
-    const int n0 = min(t_begin * 16 + kk, g.N - 1);
-    gq_b = n0 / g.S_o;
-    gq_pix = n0 - gq_b * g.S_o;
-  }
-  float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
-
   f32x16 acc[MB][NBW];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
@@ -138,38 +115,8 @@ __global__ __launch_bounds__(256, NBW == 4 ? 2 : 1) void mfma_bwd_weight_cl_kern
     for (int h = 0; h < NH; ++h)
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci) rg[h][ci] = buf_load4(r_xt, tb.off[ci] + c_voff + h * 256, 0);
-    if (COORD) {   // called once per chunk, in chunk order: advance the pixel after the request
-      if (do_coord) gq = buf_load4(r_gc, ((gq_b * g.K + tap) * g.S_o + gq_pix) * g.C * 4 + c_voff, 0);
-      gq_pix += 16;
-      if (gq_pix >= g.S_o) { gq_pix -= g.S_o; ++gq_b; }
-      if (gq_b >= g.B) { gq_b = g.B - 1; gq_pix = g.S_o - 1; }   // (harmless re-requests past the end)
-    }
-  };
-  auto coord_sums = [&](int t) {
-    float S[NC];
-#pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {
-      const float4 x = rg[0][ci];
-      S[ci] = fmaf(gq.w, x.w, fmaf(gq.z, x.z, fmaf(gq.y, x.y, gq.x * x.x)));
-    }
-#pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {   // sum over the 16 lanes of the pixel = one DPP row
-      S[ci] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, S[ci]), 0xB1, 0xf, 0xf, true));
-      S[ci] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, S[ci]), 0x4E, 0xf, 0xf, true));
-      S[ci] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, S[ci]), 0x141, 0xf, 0xf, true));
-      S[ci] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, S[ci]), 0x140, 0xf, 0xf, true));
-    }
-    const int n = t * 16 + kk;
-    if (cq == 0 && n < g.N) {
-      float4 *dst = reinterpret_cast<float4 *>(sbuf + (((size_t)cblk * g.K + tap) * bd.Np + n) * NC);
-#pragma unroll
-      for (int c4 = 0; c4 < NC; c4 += 4) dst[c4 / 4] = make_float4(S[c4], S[c4 + 1], S[c4 + 2], S[c4 + 3]);
-    }
   };
   auto commit = [&](const Tab &tb, int t, float *Bb) {
-    if (COORD) {
-      if (do_coord) coord_sums(t);
-    }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -304,50 +251,42 @@ namespace mdconv {
 
 // Resident workgroups per CU of the variant that (nd, padn, wtile, coord) selects: hipOccupancy on the very
 // instance, so the split-K count of bwd_dims() follows the register allocation instead of a constant that rots.
-#define MDCONV_CL_INSTANCE(ND, PADN, COORD, CALL)                                                              \
+#define MDCONV_CL_INSTANCE(ND, PADN, CALL)                                                                     \
   do {                                                                                                          \
-    if (wtile == 1) { CALL(ND, PADN, 2, 2, 1, 1, COORD); }                                                      \
-    else if (wtile == 2) { CALL(ND, PADN, 2, 2, 2, 1, COORD); }                                                 \
-    else if (wtile == 4) { CALL(ND, PADN, 4, 1, 2, 4, false); }                                                 \
-    else { CALL(ND, PADN, 4, 1, 2, 2, COORD); }                                                                 \
+    if (wtile == 1) { CALL(ND, PADN, 2, 2, 1, 1); }                                                             \
+    else if (wtile == 2) { CALL(ND, PADN, 2, 2, 2, 1); }                                                        \
+    else { CALL(ND, PADN, 4, 1, 2, 2); }                                                                        \
   } while (0)
 #define MDCONV_CL_DISPATCH(CALL)                                                                               \
   do {                                                                                                          \
-    if (nd == 2) {                                                                                              \
-      if (coord) { if (padn) MDCONV_CL_INSTANCE(2, true, true, CALL); else MDCONV_CL_INSTANCE(2, false, true, CALL); } \
-      else { if (padn) MDCONV_CL_INSTANCE(2, true, false, CALL); else MDCONV_CL_INSTANCE(2, false, false, CALL); }     \
-    } else {                                                                                                    \
-      if (padn) MDCONV_CL_INSTANCE(3, true, false, CALL); else MDCONV_CL_INSTANCE(3, false, false, CALL);       \
-    }                                                                                                           \
+    if (nd == 2) { if (padn) MDCONV_CL_INSTANCE(2, true, CALL); else MDCONV_CL_INSTANCE(2, false, CALL); }      \
+    else { if (padn) MDCONV_CL_INSTANCE(3, true, CALL); else MDCONV_CL_INSTANCE(3, false, CALL); }              \
   } while (0)
 
-int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile, bool coord) {
-  static int cache[2][2][5][2] = {};
-  if (nd != 2 || wtile == 4) coord = false;
-  int &slot = cache[nd == 3][padn][wtile < 0 || wtile > 4 ? 3 : wtile][coord];
+int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile) {
+  static int cache[2][2][4] = {};
+  int &slot = cache[nd == 3][padn][wtile < 0 || wtile > 3 ? 3 : wtile];
   if (slot) return slot;
   int n = 0;
-#define OCC_CL(ND, PADN, WR, WC, MB, NBW, COORD)                                                               \
+#define OCC_CL(ND, PADN, WR, WC, MB, NBW)                                                                      \
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                                          \
-      &n, reinterpret_cast<const void *>(&mfma_bwd_weight_cl_kernel<ND, PADN, WR, WC, MB, NBW, COORD>), 256, 0)
+      &n, reinterpret_cast<const void *>(&mfma_bwd_weight_cl_kernel<ND, PADN, WR, WC, MB, NBW>), 256, 0)
   MDCONV_CL_DISPATCH(OCC_CL);
 #undef OCC_CL
   (void)hipGetLastError();
-  if (n <= 0) n = wtile == 4 ? 2 : 3;   // no device (host-only tests): the figures of the committed build
+  if (n <= 0) n = 3;   // no device (host-only tests): the figures of the committed build
   slot = n;
   return n;
 }
 
-// gcol / sbuf: grad_col rows and the corner-sum partials of the COORD variant (bd.split_drain == 2), else unused
 int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt, const float *ga,
-                              const int *table, float *part, const float *gcol, float *sbuf, hipStream_t stream) {
+                              const int *table, float *part, hipStream_t stream) {
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
   const bool padn = bd.Np != g.N;
   const int nd = g.nd, wtile = bd.wtile;
-  const bool coord = bd.split_drain == 2 && nd == 2 && wtile != 4;
-#define LAUNCH_CL(ND, PADN, WR, WC, MB, NBW, COORD)                                                            \
-  hipLaunchKernelGGL((mfma_bwd_weight_cl_kernel<ND, PADN, WR, WC, MB, NBW, COORD>), grid, dim3(256), 0,        \
-                     stream, g, bd, xt, ga, table, part, gcol, sbuf)
+#define LAUNCH_CL(ND, PADN, WR, WC, MB, NBW)                                                                   \
+  hipLaunchKernelGGL((mfma_bwd_weight_cl_kernel<ND, PADN, WR, WC, MB, NBW>), grid, dim3(256), 0,               \
+                     stream, g, bd, xt, ga, table, part)
   MDCONV_CL_DISPATCH(LAUNCH_CL);
 #undef LAUNCH_CL
   return check_launch("mfma_bwd_weight_cl");

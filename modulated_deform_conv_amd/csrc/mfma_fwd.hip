@@ -381,6 +381,8 @@ __global__ __launch_bounds__(256) void fwd_tail_reduce_kernel(Geom g, const floa
   }
 }
 
+constexpr int kTailMaxPerCu = 5;   // resident workgroups per CU the tail plan and its scratch are sized for
+
 // Tail plan of a tile grid (see the kernel): tiles that fill whole dispatch rounds, and the number of tap ranges
 // the leftover tiles are cut into so that their workgroups still fit one round.  MDCONV_FWD_TAIL=0 disables.
 void fwd_tail_plan(const Geom &g, int tiles, int slots, int *full_tiles, int *ways) {
@@ -411,7 +413,9 @@ int fwd_tile_slots() {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &n, reinterpret_cast<const void *>(&mfma_fwd_kernel<ND, MOD, BM, BN, WM, WN, PADK>), 256, 0);
     (void)hipGetLastError();
-    slots = device_cus() * (n > 0 ? n : 3);
+    // clamped to kTailMaxPerCu: the tail scratch (fwd_tail_bytes) holds one partial tile per slot, and the tail never
+    // has more workgroups than slots (advisor, round 4: an instance that got leaner would otherwise overrun it)
+    slots = device_cus() * (n > 0 ? (n < kTailMaxPerCu ? n : kTailMaxPerCu) : 3);
   }
   return slots;
 }
@@ -476,7 +480,7 @@ namespace mdconv {
 // scratch for the tap-range partials of the tail tiles: at most one partial tile (every tile shape is 8192
 // floats) per resident workgroup, 5 of them per CU at the very most
 size_t fwd_tail_bytes(const Geom &g) {
-  return g.G == 1 && g.K >= 2 ? (size_t)device_cus() * 5 * 8192 * sizeof(float) : 0;
+  return g.G == 1 && g.K >= 2 ? (size_t)device_cus() * kTailMaxPerCu * 8192 * sizeof(float) : 0;
 }
 
 int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,

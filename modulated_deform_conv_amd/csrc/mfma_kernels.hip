@@ -127,28 +127,8 @@ BwdDims bwd_dims(const Geom &g) {
   static const int bw_tile_env = getenv("MDCONV_BW_TILE") ? atoi(getenv("MDCONV_BW_TILE")) : 0;
   if (bw_tile_env == 1 && g.O <= 64) bd.wtile = 1;
   if (bd.cl) bd.wtile = g.O <= 64 ? 1 : (g.O <= 128 ? 2 : 3);
-  // 256 x 128 tile (wtile 4): the A fragments and the per-chunk barrier amortised over twice the matrix work
-  // (GEMM-2's time sits in issuing its loads); needs 128-channel blocks inside one
-  // deformable group and one conv group
-  static const int bw_wide_env = getenv("MDCONV_BW_WIDE") ? atoi(getenv("MDCONV_BW_WIDE")) : 0;
-  if (bd.cl && bd.wtile == 3 && bw_wide_env && g.nd == 2 && g.G == 1 && g.C % 128 == 0 && (g.DG == 1 || g.Cdg % 128 == 0)) bd.wtile = 4;   // (3-D: 192 bytes of scratch at two workgroups per CU)
-  // Drain of GEMM-1 (grad_offset / grad_mask): 0 = fused into GEMM-1 (the default: at cfg2
-  // the fused kernel hides 0.31 ms of drain in 0.18 ms), 1 = own kernel beside GEMM-2 (mfma_coord.hip), 2 = corner
-  // sums inside the channels-last GEMM-2 + a finishing pass (2-D).  Both split forms are parity-green and measured
-  // SLOWER (backward 2.38 / 2.60 ms against 2.22 at cfg2): opt-in experiments, MDCONV_BD_SPLIT = 1 | 2, available
-  // where the backward has the channels-last copy and a deformable group is a whole number of 64-channel blocks.
-  {
-    static const int bd_split_env = getenv("MDCONV_BD_SPLIT") ? atoi(getenv("MDCONV_BD_SPLIT")) : -1;
-    int mode = 0;
-    if (bd.cl && (g.DG == 1 || g.Cdg % 64 == 0)) {
-      mode = bd_split_env >= 0 ? bd_split_env : 0;
-      if (mode == 2 && (g.nd != 2 || bd.wtile == 4)) mode = 0;
-      if (mode < 0 || mode > 2) mode = 0;
-    }
-    bd.split_drain = mode;
-  }
   const int rm = bd.cl ? (bd.wtile == 1 ? 64 : (bd.wtile == 2 ? 128 : 256)) : (bd.wtile ? 64 : 256);
-  const int cn = bd.cl ? (bd.wtile == 4 ? 128 : 64) : (bd.wtile ? 64 : 32);
+  const int cn = bd.cl ? 64 : (bd.wtile ? 64 : 32);
   bd.OgpB = (g.O + rm - 1) / rm * rm;
   bd.mblks = bd.OgpB / 32;
   bd.mtiles = bd.OgpB / rm;
@@ -162,7 +142,7 @@ BwdDims bwd_dims(const Geom &g) {
   // reaches 0.8+.  slots = CUs x resident workgroups of the instance that will run (hipOccupancy).
   // MDCONV_BW_SPLITS overrides (experiments).
   const bool padn = bd.Np != g.N;
-  const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile, bd.split_drain == 2)
+  const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile)
                         : mfma_bwd_weight_occupancy(g.nd, padn, bd.wtile);
   // ... minus one per CU when the grad_input gather runs beside this kernel on the forked stream: a full round of
   // 164-register workgroups leaves the gather no wave slot until the round retires, and the two tails then run one
@@ -210,7 +190,6 @@ BwdDims bwd_dims(const Geom &g) {
       bd.cl_drain = 0;
       size_red();
     }
-    if (bd.split_drain) { bd.cl_drain = 0; bd.red_floats = 0; bd.tap_group = 9; }
   }
   const int nc = 1 << g.nd;
   size_t off = 0;
@@ -232,7 +211,6 @@ BwdDims bwd_dims(const Geom &g) {
   static const int c2i_env = getenv("MDCONV_C2I3D") ? atoi(getenv("MDCONV_C2I3D")) : 2;
   bd.two_pass = bd.sample_keyed && c2i_env >= 2 ? 1 : 0;
   bd.off_sums = off; off += bd.two_pass ? align_up(col2im3d_sums_bytes(g)) : 0;
-  bd.off_sbuf = off; off += bd.split_drain == 2 ? align_up((size_t)bd.cblks * g.K * bd.Np * nc * sizeof(float)) : 0;
   bd.off_end = off;
   return bd;
 }
@@ -376,7 +354,7 @@ int narrow(int dtype, const float *src, void *dst, int64_t n, bool accum, hipStr
 // grad_input gather (CSR build + col2im, HBM-bound) needs GEMM-1's grad_col and counters only, GEMM-2
 // (matrix-bound) needs GEMM-1's packed grad_out and tap table only.  One side stream and two events
 // per (device, caller stream), created on first use and kept (bounded like the weights-ready events).
-struct Fork { hipStream_t side; hipEvent_t fork, join, table, gemm1; };
+struct Fork { hipStream_t side; hipEvent_t fork, join; };
 std::mutex g_fork_mu;
 std::vector<std::pair<std::pair<int, hipStream_t>, Fork>> g_forks;
 bool get_fork(hipStream_t stream, Fork *out) {
@@ -399,9 +377,7 @@ bool get_fork(hipStream_t stream, Fork *out) {
   const int prio = prio_env < 0 ? greatest : (prio_env > 0 ? least : 0);
   if (hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, prio) != hipSuccess) return false;
   if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&f.table, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&f.gemm1, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess)
     return false;
   g_forks.push_back({{dev, stream}, f});
   *out = f;
@@ -444,69 +420,6 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   // channels-last copy of the input for the 3-D gathers of GEMM-1's drain and of GEMM-2
   float *xt = bd.cl ? (float *)(base + bd.off_xt) : nullptr;
   if (bd.cl && (rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream))) return rc;
-  if (bd.split_drain) {
-    // Split drain (mfma_coord.hip).  Two chains, joined before the return:
-    //   caller's stream:  GEMM-1 (pure: grad_col stream, packed grad_out, grad_bias partials) -> GEMM-2 -> reduce
-    //   side stream:      tap table + counting -> scan -> fill   [offset / mask only: beside GEMM-1]
-    //                     -> coordinate gradients -> grad_input gather   [need grad_col: beside GEMM-2]
-    // GEMM-2 waits for the tap table, the coordinate gradients for GEMM-1.  Without the fork (MDCONV_BWD_FORK=0 or
-    // no side stream) the same kernels run one after the other.
-    Fork fk;
-    const bool fork = bwd_fork_enabled() && get_fork(stream, &fk);
-    hipStream_t ss = fork ? fk.side : stream;
-    auto hip_ok = [](hipError_t e) { return e == hipSuccess; };
-    if (fork && !(hip_ok(hipEventRecord(fk.fork, stream)) && hip_ok(hipStreamWaitEvent(fk.side, fk.fork, 0)))) {
-      set_error("backward fork failed");
-      return MDCONV_ELAUNCH;
-    }
-    rc = tap_prepass_f32(g, bd, t, cnt, table, ss);
-    if (!rc && fork && !hip_ok(hipEventRecord(fk.table, fk.side))) { set_error("backward fork failed"); rc = MDCONV_ELAUNCH; }
-    if (!rc) rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, ss);
-    if (!rc) {
-      profile_mark(1, true, stream, "mfma_bwd_data_kernel");
-      rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, stream);
-      profile_mark(1, false, stream);
-    }
-    if (!rc && fork &&
-        !(hip_ok(hipEventRecord(fk.gemm1, stream)) && hip_ok(hipStreamWaitEvent(fk.side, fk.gemm1, 0)) &&
-          hip_ok(hipStreamWaitEvent(stream, fk.table, 0)))) {
-      set_error("backward fork failed");
-      rc = MDCONV_ELAUNCH;
-    }
-    const bool in_gemm2 = bd.split_drain == 2;
-    float *sbuf = in_gemm2 ? (float *)(base + bd.off_sbuf) : nullptr;
-    auto shadow = [&]() {
-      int r;
-      if (!in_gemm2) {
-        profile_mark(4, true, ss, "coord_grad_kernel");
-        r = coord_grad_f32(g, bd, t, gcol, xt, ss);
-        profile_mark(4, false, ss);
-        if (r) return r;
-      }
-      profile_mark(3, true, ss, bd.sample_keyed ? (bd.two_pass ? "col2im3d_sums_kernel" : "col2im3d_kernel") : "col2im_gather_kernel");
-      r = col2im_f32(g, bd, t, gcol, rowptr, entries, (float *)(base + bd.off_sums), ss);
-      profile_mark(3, false, ss);
-      return r;
-    };
-    // enqueue order = dispatch order when both queues are ready: MDCONV_BWD_FORK=2 puts GEMM-2 first
-    const bool gemm2_first = fork && bwd_fork_mode() == 2;
-    if (!rc && !gemm2_first) rc = shadow();
-    if (!rc) rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream, in_gemm2 ? gcol : nullptr, sbuf);
-    if (!rc && weights_final) rc = record_weight_ready(stream);
-    if (!rc && in_gemm2) {
-      profile_mark(4, true, stream, "coord_finish_kernel");
-      rc = coord_finish_f32(g, bd, t, sbuf, stream);
-      profile_mark(4, false, stream);
-    }
-    if (!rc && gemm2_first) rc = shadow();
-    // join on every path once the side stream has work (an unjoined fork would leave the side stream writing the
-    // caller's buffers after the return, and an open capture invalid)
-    if (fork && !(hip_ok(hipEventRecord(fk.join, fk.side)) && hip_ok(hipStreamWaitEvent(stream, fk.join, 0))) && !rc) {
-      set_error("backward join failed");
-      rc = MDCONV_ELAUNCH;
-    }
-    return rc;
-  }
   profile_mark(1, true, stream, "mfma_bwd_data_kernel");
   rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, stream);
   profile_mark(1, false, stream);

@@ -84,13 +84,10 @@ struct BwdDims {
   int red_floats;       // GEMM-1: floats of the grad_offset / grad_mask reduction buffer in LDS
   int tap_group;        // GEMM-1: taps per flush of that buffer (9; 3 where LDS is short)
   int cl_drain;         // GEMM-1 drains through the channels-last copy (line-wide gathers)
-  int split_drain;      // GEMM-1 is the pure GEMM + grad_col stream, the tap table / counting pass its own kernel;
-                        // the coordinate gradients: 1 = their own kernel beside GEMM-2 (mfma_coord.hip, opt-in),
-                        // 2 = corner sums inside the channels-last GEMM-2 + a small finishing pass (2-D default)
   int sample_keyed;     // scatter lists: 1 = one entry per SAMPLE (3-D, mfma_csr3d.hip), 0 = per corner pair
   int S_e;              // list heads per (image, deformable group): anchor space (3-D) or S_i
   size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
-      off_xt, off_sums, off_sbuf, off_end;   // off_sbuf: corner-sum partials [cblk][tap][Np][2^nd] (split_drain == 2)   // off_sums: per-anchor partial sums of the two-pass 3-D gather (0 bytes otherwise)
+      off_xt, off_sums, off_end;   // off_sums: per-anchor partial sums of the two-pass 3-D gather (0 bytes otherwise)
   int two_pass;         // 3-D grad_input gather: 1 = per-anchor partial sums + stencil (mfma_csr3d.hip), 0 = block walk
 };
 BwdDims bwd_dims(const Geom &g);
@@ -114,15 +111,14 @@ bool fwd_channels_last(const Geom &g);
 size_t fwd_cl_bytes(const Geom &g);
 int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
                         float *xt, hipStream_t stream);
-// gcol / sbuf: only for bd.split_drain == 2 (corner sums inside the channels-last GEMM-2), else nullptr
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, const float *xt,
-                        hipStream_t stream, const float *gcol = nullptr, float *sbuf = nullptr);
+                        hipStream_t stream);
 int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt, const float *ga,
-                              const int *table, float *part, const float *gcol, float *sbuf, hipStream_t stream);
+                              const int *table, float *part, hipStream_t stream);
 // resident workgroups per CU of the GEMM-2 instance a shape selects (hipOccupancy, cached); device_cus() = CUs of
 // the current device (256 on MI355X; the same figure without a device, for host-only callers)
-int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile, bool coord);
+int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile);
 int mfma_bwd_weight_occupancy(int nd, bool padn, int wtile);
 int device_cus();
 bool bwd_channels_last(const Geom &g);
@@ -137,13 +133,6 @@ int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, 
                   void *entries, hipStream_t stream);
 int col2im_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol,
                const int *rowptr, const void *entries, float *sums, hipStream_t stream);
-// split drain (mfma_coord.hip): tap table for the channels-last GEMM-2 + the counting pass of the scatter lists,
-// and grad_offset / grad_mask from the grad_col rows and the channels-last input copy
-int tap_prepass_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, int *table, hipStream_t stream);
-int coord_grad_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *gcol, const float *xt,
-                   hipStream_t stream);
-// split_drain == 2: grad_offset / grad_mask from the 64-channel corner-sum partials GEMM-2 left in sbuf
-int coord_finish_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *sbuf, hipStream_t stream);
 // 3-D: scatter lists keyed by sample (mfma_csr3d.hip)
 int csr_fill3d_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cursor,
                    const int *rowptr, void *entries, hipStream_t stream);

@@ -20,19 +20,3 @@ def test_parity_with_channels_last_kernels_forced():
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
-
-
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_parity_with_the_split_drains_of_gemm1(mode):
-    """The two opt-in placements of GEMM-1's drain: MDCONV_BD_SPLIT=1 -- tap pre-pass +
-    coordinate-gradient kernel beside GEMM-2 (mfma_coord.hip); 2 -- corner sums inside the channels-last GEMM-2 + a
-    finishing pass (2-D).  Both need the channels-last backward, hence MDCONV_BWD_CL=1 for the small parity shapes.
-    They are slower than the fused kernel and off by default, but they are product code: same oracle, same cases,
-    the analytic pins and a non-finite border pixel included."""
-    env = dict(os.environ, MDCONV_BD_SPLIT=mode, MDCONV_BWD_CL="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_analytic_pins.py",
-                        "-m", "gpu", "-q", "-x", "-k", "auto_path or mfma_path or overwrite or float32-auto or cl-mfma"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout

@@ -8,7 +8,7 @@
 The product runs the FULL shard (forward and backward); the oracle is too slow for a whole shard,
 but every per-image result (output, grad_input, grad_offset, grad_mask) depends on that image
 only (mdeformable_conv.cu:54, 64-66, 228), so image 0 and the last image are compared against the
-oracle run on those one-image slices.  grad_weight / grad_bias sum over the batch
+oracle run on those one-image slices, and EVERY image of the shard against a one-image run of the product.  grad_weight / grad_bias sum over the batch
 (mdeformable_conv.cu:436-444): they are checked on the first two images (product B=2 vs oracle
 B=2) and, at full size, by additivity over the two half shards.
 Tolerances: 1e-4 fp32, 5e-3 fp16 (fp32 oracle on the fp16-rounded inputs), both criteria of
@@ -82,6 +82,13 @@ def _check_config(op, B, C, O, sp, nd, modulated, groups, dgroups, dtype, pad, d
         want = _oracle(op, sl(x, s), sl(off, s), sl(m, s), w, sl(go, s), pad, dil, groups, dgroups)
         for name in per_image:
             assert_close("%s[%d]" % (name, img), full[name][s].float(), want[name], tol)
+    # EVERY image of the full-shard run vs a one-image product run (images 0 and B-1 of the full run were just checked
+    # against the oracle): a tile-tail, tile-order or batch-chunk-boundary bug in the middle of the batch cannot pass
+    for img in range(B):
+        s = slice(img, img + 1)
+        one, _ = _product(op, sl(x, s), sl(off, s), sl(m, s), w, sl(go, s), geo)
+        for name in per_image:
+            assert_close("%s[%d] one-image run vs shard" % (name, img), one[name].float(), full[name][s].float(), tol * 0.5)
     # grad_weight on the first two images: product B=2 vs oracle B=2 (the sum over the batch)
     s = slice(0, 2)
     two, _ = _product(op, sl(x, s), sl(off, s), sl(m, s), w, sl(go, s), geo)

@@ -103,6 +103,37 @@ def test_cfg2_linearity_shards_instep_determinism(cfg2):
     assert_close("grad_bias", parts[0][1][4] + parts[1][1][4], g[4], 1e-4)
 
 
+BITSTABLE_CODE = r"""
+import sys
+sys.path.insert(0, %r)
+import torch
+from tests.test_gpu_fullsize import _inputs, _mdcn2d
+x, off, m, w, b, go = _inputs(32, 256, 256, (56, 56), 9, 2, True)
+out, g, _ = _mdcn2d(x, off, m, w, b, go, "auto")
+h = 16
+parts = [_mdcn2d(x[s].contiguous(), off[s].contiguous(), m[s].contiguous(), w, b, go[s].contiguous(), "auto")
+         for s in (slice(0, h), slice(h, None))]
+assert torch.equal(torch.cat([p[0] for p in parts]), out), "output"
+assert torch.equal(torch.cat([p[1][1] for p in parts]), g[1]), "grad_offset"
+assert torch.equal(torch.cat([p[1][2] for p in parts]), g[2]), "grad_mask"
+print("BITSTABLE_OK")
+"""
+
+
+def test_cfg2_shards_are_bit_identical_with_the_forward_tail_split_off():
+    """MDCONV_FWD_TAIL=0 is the bit-stable switch INTEGRATION.md names: without the tap-range tail of the forward's
+    last dispatch round (whose tile selection follows batch size, CU count and occupancy) the output of a batch shard
+    equals the full-batch output bit for bit, and so do grad_offset / grad_mask (single owner per (tap, pixel), fixed
+    K order); read once per process, hence a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", BITSTABLE_CODE % root], cwd=root, env=dict(os.environ, MDCONV_FWD_TAIL="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BITSTABLE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 # --------------------------------------------------------------------------- cfg4 (3-D, trilinear)
 def test_cfg4_deform_conv3d_mfma_equals_direct_and_conv3d():
     """DeformConv3d 3x3x3, C=64, 32^3, B=8, fp32 (BASELINE.json configs[3])."""

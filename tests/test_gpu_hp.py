@@ -47,6 +47,8 @@ HP_CASES = [
     _c("hp_dcn3d_c32_o200", D3, 1, 32, 200, (3, 5, 6), 3, bias=False, seed=122),
 ]
 
+CASE_BY_HP = {c["name"]: c for c in HP_CASES}
+
 # 16-bit shapes the native kernels reject in at least one direction (hp_supported): more than 256
 # input channels / a block's output range above 256 in the backward, deformable groups of 16
 # channels.  fp16 AND bf16 must still work (fp32 copies through the fp32 kernels, else the
@@ -142,6 +144,28 @@ def test_medium_cases_fp16(case):
     worst case of this list (stride-2 3-D, grad_input: sums of fp16-rounded grad_col rows with
     cancellation) measures 7.3e-3 on the per-element criterion."""
     _check(case, torch.float16, expect_hp=False, tol=1e-2)
+
+
+@pytest.mark.parametrize("dtype, scale", [(torch.bfloat16, 1.0e5), (torch.bfloat16, 1.0e-7), (torch.float16, 100.0),
+                                          (torch.float16, 1.0e-2)], ids=["bf16_1e5", "bf16_1e-7", "fp16_1e2", "fp16_1e-2"])
+@pytest.mark.parametrize("name", ["hp_mdcn2d_c256_o256_g32_dg4", "hp_mdcn2d_c64_o96_s2"])
+def test_2d_scatter_entries_carry_the_masks_range(name, dtype, scale):
+    """The 2-D scatter-list entries hold bilinear weight x MASK products as packed 16-bit pairs (hp_col2im.hip).  They
+    are packed in the tensors' own type, so a bf16 mask of 1e5 (above the fp16 range) or 1e-7 (products below the
+    fp16 subnormals) scales grad_input like any other mask (advisor, round 4); fp16 masks inside the fp16 range too."""
+    from modulated_deform_conv_amd import _capi
+    case = CASE_BY_HP[name]
+    t = make_inputs(case, dtype=dtype, device="cuda")
+    t["mask"] = (t["mask"].float() * scale).to(dtype)
+    out, grads, _ = run_product(case, t, "auto")
+    torch.cuda.synchronize()
+    assert _capi.last_kernels() == "hp"
+    want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
+    assert_close("output", out.float(), want_out, TOL[dtype])
+    for key in ("grad_input", "grad_offset", "grad_weight"):
+        assert_close(key, grads[key].float(), want[key], TOL[dtype])
+    # grad_mask does not scale with the mask: compare it relative to the (unscaled) oracle as usual
+    assert_close("grad_mask", grads["grad_mask"].float(), want["grad_mask"], TOL[dtype])
 
 
 def test_non_finite_border_pixel_is_not_read():
