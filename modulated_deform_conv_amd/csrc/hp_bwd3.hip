@@ -46,6 +46,14 @@ __device__ unsigned long long g_b3_timing[8];
 
 
 constexpr int kChunkRows = 64;   // grad_out rows staged through LDS at a time (4 k-steps)
+// Sampling states are built TWO taps at a time (round 5): at an even tap t lanes 0-31 build (t, pixel) and lanes
+// 32-63 build (t + 1, pixel) -- before, both half-waves computed the same state and one discarded it.  The state
+// table has one row set per wave, so lanes 32-63 keep their row in registers (18 dwords) until tap t + 1 starts;
+// the per-axis factors `fac` stay in the half-wave that built them, which is also the one that finishes the tap's
+// grad_offset / grad_mask.  B3_PAIR=0 restores one build per tap (A/B switch).
+#ifndef B3_PAIR
+#define B3_PAIR 1
+#endif
 
 template <int ND, bool MOD, typename T, int LPP, int NKS>
 __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
@@ -143,19 +151,57 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
   Raw dlr[ND], mlr;
   const Raw *off_px = offset + (int64_t)b * (ND * g.K) * g.S_o + pix;
   const Raw *msk_px = MOD ? mask + (int64_t)b * g.K * g.S_o + pix : nullptr;
+#if B3_PAIR
+  // the tap THIS lane builds next (lanes 32-63 one ahead), its coordinates kept incrementally
+  int b_tap = kh, b_tcd[ND];
+  {
+    int t0[ND];
+    tap_coords<ND>(g, min(kh, g.K - 1), t0);   // (lane-dependent only through kh: two integer divisions, once)
+#pragma unroll
+    for (int a = 0; a < ND; ++a) b_tcd[a] = t0[a];
+  }
+  auto advance2 = [&]() {
+    b_tap += 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (++b_tcd[ND - 1] == g.ksz[ND - 1]) {
+        b_tcd[ND - 1] = 0;
+        if (ND == 3) {
+          if (++b_tcd[1] == g.ksz[1]) { b_tcd[1] = 0; ++b_tcd[0]; }
+        } else {
+          ++b_tcd[0];
+        }
+      }
+    }
+  };
+  auto fetch = [&]() {   // offsets / mask of this lane's next tap (clamped past the last: built, never used)
+    const int tp = min(b_tap, g.K - 1);
+#pragma unroll
+    for (int a = 0; a < ND; ++a) dlr[a] = off_px[((int64_t)tp * ND + a) * g.S_o];
+    if (MOD) mlr = msk_px[(int64_t)tp * g.S_o];
+  };
+#else
   auto fetch = [&](int tap) {
 #pragma unroll
     for (int a = 0; a < ND; ++a) dlr[a] = off_px[((int64_t)tap * ND + a) * g.S_o];
     if (MOD) mlr = msk_px[(int64_t)tap * g.S_o];
   };
+#endif
   struct Fac { float wl[ND], wh[ND], sl[ND], sh[ND], mg; } fac;
-  auto build = [&](int tap) {   // sampling state of (tap, this lane's pixel) from dl / ml -> St row; CSR counting
+  int held[SW];   // B3_PAIR: the state row lanes 32-63 built for the odd tap, until that tap starts
+#pragma unroll
+  for (int q = 0; q < SW; ++q) held[q] = 0;
+  auto store_row = [&](const int (&ev)[SW]) {
+    int *sp = St + pl * SW;
+#pragma unroll
+    for (int q = 0; q < SW; q += 4) *reinterpret_cast<int4 *>(sp + q) = make_int4(ev[q], ev[q + 1], ev[q + 2], ev[q + 3]);
+  };
+  // sampling state of (tap, this lane's pixel) from dl / ml -> St row (or `held`); CSR counting
+  auto build_state = [&](int tap, const int *tcd, bool mine, bool hold) {
     float dl[ND], ml = 1.f;
 #pragma unroll
     for (int a = 0; a < ND; ++a) dl[a] = T::ldf(&dlr[a]);
     if (MOD) ml = T::ldf(&mlr);
-    int tcd[ND];
-    tap_coords<ND>(g, tap, tcd);
     TapCoef<ND, float> tc;
     make_tap<ND, float>(g, oc, tcd, dl, true, tc);
     HpCorners<ND> hc;
@@ -163,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     fac.mg = (!g.range_gate || tc.inside) ? ml : 0.f;
 #pragma unroll
     for (int a = 0; a < ND; ++a) { fac.wl[a] = tc.wl[a]; fac.wh[a] = tc.wh[a]; fac.sl[a] = tc.sl[a]; fac.sh[a] = tc.sh[a]; }
-    if (lane < 32) {
+    if (mine) {
       int ev[SW];
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci) {
@@ -174,9 +220,12 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
       ev[2 * NC] = live ? (tap * g.S_o + pix) * Cp * 2 : kHpOob;
       ev[2 * NC + 1] = b;
       ev[2 * NC + 2] = ev[2 * NC + 3] = 0;
-      int *sp = St + pl * SW;
+      if (hold) {
 #pragma unroll
-      for (int q = 0; q < SW; q += 4) *reinterpret_cast<int4 *>(sp + q) = make_int4(ev[q], ev[q + 1], ev[q + 2], ev[q + 3]);
+        for (int q = 0; q < SW; ++q) held[q] = ev[q];
+      } else {
+        store_row(ev);
+      }
       if (live) {
         // scatter anchor of this sample (first pass of the CSR build, hp_col2im.hip)
         SampleAnchor<ND> sa;
@@ -186,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     }
   };
   auto finish = [&](int tap) {   // grad_offset / grad_mask of (tap, this lane's pixel) from the reduced S in its state row
-    if (lane < 32 && live) {
+    if ((B3_PAIR ? kh == (tap & 1) : lane < 32) && live) {
       float S[NC];
       const int *sp = St + pl * SW;
 #pragma unroll
@@ -305,13 +354,31 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     }
   };
 
+#if B3_PAIR
+  fetch();
+#else
   fetch(0);
+#endif
   __syncthreads();   // W^T slab of tap 0 is in LDS (and every wave is past its grad_out staging)
   B3_T(6);   // prologue: W^T slab of tap 0, grad_out fragments
   for (int tap = 0; tap < g.K; ++tap) {
     if (wave_live) {
-      build(tap);
+#if B3_PAIR
+      if ((tap & 1) == 0) {
+        build_state(b_tap, b_tcd, b_tap < g.K, kh != 0);
+        advance2();
+        if (tap + 2 < g.K) fetch();
+      } else if (kh) {
+        store_row(held);
+      }
+#else
+      {
+        int tcd[ND];
+        tap_coords<ND>(g, tap, tcd);
+        build_state(tap, tcd, lane < 32, false);
+      }
       if (tap + 1 < g.K) fetch(tap + 1);
+#endif
       B3_T(0);   // sampling state + next offsets
       // ---- matrix phase: GEMM-1 per 32-channel block -> Gc ----
 #pragma unroll

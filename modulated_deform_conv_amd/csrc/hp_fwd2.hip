@@ -29,6 +29,15 @@ __device__ unsigned long long g_f2_timing[8];
 
 
 constexpr int kStage = 4;    // 16-channel chunks per K stage (= 64 channels = one 128-byte line)
+// Sampling states are built TWO at a time (round 5): lanes 0-31 build state s of their pixel, lanes 32-63 state s + 1
+// (the next tap, or the next deformable group of the tap), instead of both half-waves computing the same state and
+// one of them discarding it.  The table has three slots per wave (state s lives in slot s % 3): when the pair
+// (s + 2, s + 3) is built, during the last stage of state s + 1, the slots of s + 2 and of s (done) are free.
+// F2_PAIR=0 restores one state per build and two slots (A/B switch).
+#ifndef F2_PAIR
+#define F2_PAIR 1
+#endif
+constexpr int kStSlots = F2_PAIR ? 3 : 2;
 constexpr int kBtP = 72;     // LDS pitch (16-bit elements) of a pixel row of the B tile: 64 + 8
 
 // GRP = false: one conv group -- every chunk feeds every output-channel block, no table lookups.
@@ -45,13 +54,13 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
   const int nmax = GRP ? hd.fwd_nmax : MB;
   U4 *As = reinterpret_cast<U4 *>(smem);                                   // [2][kStage][nmax][64]
   Raw *Bt_all = reinterpret_cast<Raw *>(As + 2 * kStage * nmax * 64);      // [4][32][kBtP]
-  int *St_all = reinterpret_cast<int *>(Bt_all + 4 * 32 * kBtP);           // [4][2][32][SW]
+  int *St_all = reinterpret_cast<int *>(Bt_all + 4 * 32 * kBtP);           // [4][kStSlots][32][SW]
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int gp = lane >> 3, oc8 = lane & 7;   // gather role: pixel within a group of 8, channel octet
   Raw *Bt = Bt_all + wave * 32 * kBtP;
-  int *St = St_all + wave * 2 * 32 * SW;
+  int *St = St_all + wave * kStSlots * 32 * SW;
   const int orange = blockIdx.y;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int nchunks = hd.Cp / 16;
@@ -104,13 +113,71 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
   Raw dlr[ND], mlr;
   const Raw *off_px = offset + (int64_t)b * g.DG * (ND * g.K) * g.S_o + pix;
   const Raw *msk_px = MOD ? mask + (int64_t)b * g.DG * g.K * g.S_o + pix : nullptr;
+  const int px_base = b * g.S_i;
+  auto store_state = [&](const TapCoef<ND, float> &tc, float ml, int slot) {
+    HpCorners<ND> hc;
+    hp_corners<ND>(tc, hc);
+    int *sp = St + (slot * 32 + (lane & 31)) * SW;
+    int ev[SW];
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+      ev[ci] = hc.idx[ci] >= 0 ? (px_base + hc.idx[ci]) * hd.Cp * 2 : kHpOob;
+      ev[NC + ci] = __float_as_int(hc.w[ci] * ml);
+    }
+#pragma unroll
+    for (int q = 0; q < SW; q += 4) *reinterpret_cast<int4 *>(sp + q) = make_int4(ev[q], ev[q + 1], ev[q + 2], ev[q + 3]);
+  };
+#if F2_PAIR
+  // states of a tap: one per run of `spd` stages (deformable group); state index = tap * ndg + run
+  const int ndg = g.DG == 1 ? 1 : (nst + spd - 1) / spd;
+  const int nstates = g.K * ndg;
+  // the state THIS lane builds next: (b_tap, b_run) with the tap's coordinates kept incrementally (a per-lane tap
+  // would otherwise cost two integer divisions per build); lanes 32-63 start one state ahead of lanes 0-31
+  int b_tap = 0, b_run = 0, b_tcd[ND];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) b_tcd[a] = 0;
+  auto advance = [&]() {   // one state further
+    if (++b_run == ndg) {
+      b_run = 0;
+      ++b_tap;
+      if (++b_tcd[ND - 1] == g.ksz[ND - 1]) {
+        b_tcd[ND - 1] = 0;
+        if (ND == 3) {
+          if (++b_tcd[1] == g.ksz[1]) { b_tcd[1] = 0; ++b_tcd[0]; }
+        } else {
+          ++b_tcd[0];
+        }
+      }
+    }
+  };
+  if (kh) advance();
+  auto fetch_pair = [&]() {   // offsets / mask of this lane's next state (clamped past the last one: built, never read)
+    const int tp = min(b_tap, g.K - 1);
+    const int idx = (dg0 + b_run) * g.K + tp;
+    const Raw *op = off_px + (int64_t)idx * (ND * g.S_o);
+#pragma unroll
+    for (int a = 0; a < ND; ++a) dlr[a] = op[(int64_t)a * g.S_o];
+    if (MOD) mlr = msk_px[(int64_t)idx * g.S_o];
+  };
+  auto build_pair = [&](int sig0) {   // states sig0 (lanes 0-31) and sig0 + 1 (lanes 32-63) from the fetched values
+    float dl[ND], ml = 1.f;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(&dlr[a]);
+    if (MOD) ml = T::ldf(&mlr);
+    TapCoef<ND, float> tc;
+    make_tap<ND, float>(g, oc, b_tcd, dl, false, tc);
+    const int sg = sig0 + kh;
+    store_state(tc, ml, sg - (sg / 3) * 3);
+    advance();
+    advance();
+  };
+#else
   auto fetch = [&](int tap, int dg) {
     const Raw *op = off_px + (int64_t)(dg * g.K + tap) * ND * g.S_o;
 #pragma unroll
     for (int a = 0; a < ND; ++a) dlr[a] = op[(int64_t)a * g.S_o];
     if (MOD) mlr = msk_px[(int64_t)(dg * g.K + tap) * g.S_o];
   };
-  const int px_base = b * g.S_i;
   auto build = [&](int tap, int slot) {   // from the fetched offsets / mask
     float dl[ND], ml = 1.f;
 #pragma unroll
@@ -120,20 +187,9 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     tap_coords<ND>(g, tap, tcd);
     TapCoef<ND, float> tc;
     make_tap<ND, float>(g, oc, tcd, dl, false, tc);
-    HpCorners<ND> hc;
-    hp_corners<ND>(tc, hc);
-    if (lane < 32) {
-      int *sp = St + (slot * 32 + lane) * SW;
-      int ev[SW];
-#pragma unroll
-      for (int ci = 0; ci < NC; ++ci) {
-        ev[ci] = hc.idx[ci] >= 0 ? (px_base + hc.idx[ci]) * hd.Cp * 2 : kHpOob;
-        ev[NC + ci] = __float_as_int(hc.w[ci] * ml);
-      }
-#pragma unroll
-      for (int q = 0; q < SW; q += 4) *reinterpret_cast<int4 *>(sp + q) = make_int4(ev[q], ev[q + 1], ev[q + 2], ev[q + 3]);
-    }
+    if (lane < 32) store_state(tc, ml, slot);
   };
+#endif
 
   // ---- weight staging: fragment f of a stage = (chunk f / MB, block f % MB); wave w moves
   // fragments w, w + 4, ...; with groups only the blocks a chunk can reach, compacted ----
@@ -213,17 +269,23 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
   };
 
   // ---- prologue ----
-  fetch(0, dg0);
-  build(0, 0);
-  // position of the state AFTER the current one: (tap, dg run)
   int tap = 0, st = 0;                 // stage being processed
   int slot = 0;
+#if F2_PAIR
+  int sig = 0;                         // index of the state being processed
+  fetch_pair();
+  build_pair(0);
+  if (nstates > 2) fetch_pair();       // the pair after that
+#else
+  fetch(0, dg0);
+  build(0, 0);
   {
     // offsets / mask of the next state
     const bool more_dg = g.DG > 1 && spd < nst;
     if (more_dg) fetch(0, dg0 + 1);
     else if (g.K > 1) fetch(1, dg0);
   }
+#endif
   w_load(0, ch_lo);
   Set sa, sb;
   const int *st_lane = St + gp * SW;   // this lane's row of pixel group 0, slot 0
@@ -240,6 +302,16 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     if (st1 == nst) { st1 = 0; ++tap1; }
     const bool new_state = st1 == 0 || (g.DG > 1 && st1 % spd == 0);
     int slot_next = slot;
+#if F2_PAIR
+    if (new_state && s + 1 < S) {
+      ++sig;
+      slot_next = sig - (sig / 3) * 3;
+      if ((sig & 1) == 0) {              // states sig and sig + 1 are not built yet
+        build_pair(sig);
+        if (sig + 2 < nstates) fetch_pair();
+      }
+    }
+#else
     if (new_state && s + 1 < S) {
       slot_next = slot ^ 1;
       build(tap1, slot_next);
@@ -248,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
       if (st2 >= nst) { st2 = 0; ++tap2; }
       if (tap2 < g.K) fetch(tap2, dg0 + st2 / spd);
     }
+#endif
     F2_T(0);   // next sampling state (build) + offset / mask fetch
     const int *sp_cur = st_lane + slot * 32 * SW;
     // ---- gather + interpolate the 4 pixel groups of this stage; the first group of the next stage
@@ -339,7 +412,7 @@ namespace mdconv {
 
 size_t hp_fwd2_lds_bytes(const Geom &g, const HpDims &hd) {
   const int nc = 1 << g.nd;
-  return (size_t)2 * kStage * (g.G == 1 ? hd.MB : hd.fwd_nmax) * 1024 + (size_t)4 * 32 * kBtP * 2 + (size_t)4 * 2 * 32 * 2 * nc * 4;
+  return (size_t)2 * kStage * (g.G == 1 ? hd.MB : hd.fwd_nmax) * 1024 + (size_t)4 * 32 * kBtP * 2 + (size_t)4 * kStSlots * 32 * 2 * nc * 4;
 }
 
 template <int ND, bool MOD, typename T>
