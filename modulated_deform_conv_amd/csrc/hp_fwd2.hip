@@ -55,6 +55,15 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
   U4 *As = reinterpret_cast<U4 *>(smem);                                   // [2][kStage][nmax][64]
   Raw *Bt_all = reinterpret_cast<Raw *>(As + 2 * kStage * nmax * 64);      // [4][32][kBtP]
   int *St_all = reinterpret_cast<int *>(Bt_all + 4 * 32 * kBtP);           // [4][kStSlots][32][SW]
+#ifdef ABL_FWD_WINDOW
+  // Developer ablation (TIMING ONLY, results are wrong): what an LDS-staged input window could buy at best.  The
+  // workgroup first copies kWinFill rows of 128 bytes (a 128-pixel tile + a 4-pixel halo of one 64-channel group =
+  // 17 x 25 rows) from xt into a 32 KB LDS region (wrapping: two workgroups per CU must still fit) and then serves
+  // EVERY corner read from that region at (row index & 255) -- no window coordinates, no in-window test, no fallback
+  // path for samples outside the halo: an upper bound on the speed of such a kernel.
+  constexpr int kWinRows = 256, kWinFill = 425;
+  unsigned char *Win = reinterpret_cast<unsigned char *>(St_all + 4 * kStSlots * 32 * SW);
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,7 +257,11 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
 #ifdef ABL_FWD_NOGATHER   // developer ablation (timing only): every corner from one cache-resident row
       s.v[ci] = buf_load4u(r_xt, (ev[ci] & 0xff00) + lane_off, cbase2);
 #else
+#ifdef ABL_FWD_WINDOW
+      s.v[ci] = *reinterpret_cast<const U4 *>(Win + ((((unsigned)ev[ci] >> 9) & (kWinRows - 1)) << 7) + lane_off);
+#else
       s.v[ci] = buf_load4u(r_xt, ev[ci] + lane_off, cbase2);
+#endif
 #endif
       s.w[ci] = __int_as_float(ev[NC + ci]);
     }
@@ -268,6 +281,21 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     *reinterpret_cast<U4 *>(bt_w + pg * 8 * kBtP) = pack8<T>(col);
   };
 
+#ifdef ABL_FWD_WINDOW
+  {
+    // rows of the (fictitious) window: 17 segments of 25 consecutive pixels, one image row apart, from the tile's
+    // first pixel on (clamped into the tensor); 8 lanes per row, 16 bytes each
+    const int n0w = min(tile * 128, g.N - 1);
+    const int b0w = n0w / g.S_o, p0w = n0w - b0w * g.S_o;
+    for (int i = tid; i < kWinFill * 8; i += 256) {
+      const int row = i >> 3, piece = i & 7;
+      const int q = min(max(p0w - 4 * g.in_sz[ND - 1] - 4 + (row / 25) * g.in_sz[ND - 1] + row % 25, 0), g.S_i - 1);
+      const U4 v = buf_load4u(r_xt, (b0w * g.S_i + q) * hd.Cp * 2 + piece * 16, ch_lo * 32);
+      *reinterpret_cast<U4 *>(Win + ((row & (kWinRows - 1)) << 7) + piece * 16) = v;
+    }
+    __syncthreads();
+  }
+#endif
   // ---- prologue ----
   int tap = 0, st = 0;                 // stage being processed
   int slot = 0;
@@ -412,7 +440,12 @@ namespace mdconv {
 
 size_t hp_fwd2_lds_bytes(const Geom &g, const HpDims &hd) {
   const int nc = 1 << g.nd;
-  return (size_t)2 * kStage * (g.G == 1 ? hd.MB : hd.fwd_nmax) * 1024 + (size_t)4 * 32 * kBtP * 2 + (size_t)4 * kStSlots * 32 * 2 * nc * 4;
+#ifdef ABL_FWD_WINDOW
+  const size_t win = 256 * 128;
+#else
+  const size_t win = 0;
+#endif
+  return (size_t)2 * kStage * (g.G == 1 ? hd.MB : hd.fwd_nmax) * 1024 + (size_t)4 * 32 * kBtP * 2 + (size_t)4 * kStSlots * 32 * 2 * nc * 4 + win;
 }
 
 template <int ND, bool MOD, typename T>

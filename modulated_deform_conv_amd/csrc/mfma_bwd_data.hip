@@ -32,6 +32,8 @@
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
 #include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace mdconv {
 
@@ -68,6 +70,45 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
     }
     reinterpret_cast<float4 *>(wq)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
+}
+
+// pack_wq + counter clearing + channels-last input copy in one launch (roles by block range; see bwd_prep_f32)
+__global__ __launch_bounds__(256) void bwd_prep_kernel(Geom g, int ochunks, int cblks, const float *__restrict__ w,
+                                                       float *__restrict__ wq, int *__restrict__ cnt, int64_t cnt_n,
+                                                       const float *__restrict__ x, float *__restrict__ xt,
+                                                       int nb_pack, int nb_zero, int qtiles, int ctiles) {
+  __shared__ float t[32][33];
+  int bid = blockIdx.x;
+  if (bid < nb_pack) {
+    const int64_t total = (int64_t)g.K * ochunks * cblks * 2 * 64;   // float4 units (pack_wq_kernel)
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < total; i += (int64_t)nb_pack * 256) {
+      int64_t r = i;
+      const int lane = (int)(r & 63); r >>= 6;
+      const int q = (int)(r & 1); r >>= 1;
+      const int cblk = (int)(r % cblks); r /= cblks;
+      const int ochunk = (int)(r % ochunks);
+      const int tap = (int)(r / ochunks);
+      const int c = cblk * 32 + (lane & 31);
+      const int ob = ochunk * 16 + 8 * q + 4 * (lane >> 5);
+      float v[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int o = ob + s;
+        v[s] = (o < g.O && c < g.C && o / g.Og == c / g.Cg)
+                   ? w[((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap] : 0.f;
+      }
+      reinterpret_cast<float4 *>(wq)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return;
+  }
+  bid -= nb_pack;
+  if (bid < nb_zero) {
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < cnt_n; i += (int64_t)nb_zero * 256) cnt[i] = 0;
+    return;
+  }
+  bid -= nb_zero;
+  const int qx = bid % qtiles, cy = (bid / qtiles) % ctiles, b = bid / (qtiles * ctiles);
+  nchw_to_nhwc_tile(t, g.C, g.S_i, x, xt, b, cy * 32, qx * 32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -117,13 +158,19 @@ __device__ unsigned long long g_b1_timing[12];
 #ifndef B1_MINWAVES
 #define B1_MINWAVES 2
 #endif
-template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL>
+// COLS (round 5; channels-last drain only): the drain also forms the COLUMN rows  col[tap][n][c] = mask * sum over the
+// corners of w * x  from the corner values it has gathered anyway (+32 FMAs per lane and batch, 16 accumulators carried
+// over the 4 corner-pair batches of a half tile) and streams them to `colbuf`; GEMM-2 then is a DENSE product over
+// those rows (mfma_bwd_weight_cl.hip) instead of a third gather pass over xt -- in 3-D, where 8 corners of 256 bytes
+// per (pixel, tap) make every gathering kernel texture-path bound.  The tap table GEMM-2 used to read is not written.
+template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL, bool COLS = false>
 __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
     float *__restrict__ ga, float *__restrict__ bias_part, int *__restrict__ cnt,
-    int *__restrict__ table, const float *__restrict__ xt, int ntiles, int n_full, int n_tail, int tpw) {
+    int *__restrict__ table, const float *__restrict__ xt, float *__restrict__ colbuf, int ntiles, int n_full, int n_tail, int tpw) {
+  static_assert(!COLS || CL, "column rows come out of the channels-last drain");
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -174,13 +221,16 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
   const rsrc_t r_in = make_rsrc(CL ? xt : input, (size_t)g.B * g.C * g.S_i * 4);
   const rsrc_t r_wq = make_rsrc(wq, (size_t)g.K * T_o * chunk_bytes);
   const rsrc_t r_gc = make_rsrc(gcol, (size_t)g.B * g.C * g.K * g.S_o * 4);
+  const rsrc_t r_col = make_rsrc(COLS ? colbuf : gcol, COLS ? (size_t)g.K * bd.Np * g.C * 4 : 0);   // [tap][n][c]
+  float colacc[COLS ? 16 : 1];
   const int a_lane = lane * 16;
   const float *Bb = Gs + (wp * 32 + (lane & 31)) * gpitch + 4 * kh;
   // CL drain (line-wide gathers, see `gather`): per wave a parked-accumulator tile Pk[32][64]
   // ([pixel][channel], 16-byte pieces XOR-swizzled by the pixel so that both the accumulator-layout
   // writes and the gather-layout reads are bank-conflict free without padding), and per pixel a
   // state row St[kStRow]: 2^ND corner byte offsets into xt, the grad_col row offset, 2^ND corner sums
-  constexpr int kStRow = 2 * NC + 4;
+  // (COLS: + the 2^ND corner weights with the mask folded in; slot NC + 1 = byte offset of the pixel's column row)
+  constexpr int kStRow = 2 * NC + 4 + (COLS ? NC : 0);
   float *Pk = red + bd.red_floats + wave * (32 * 64);
   int *St = reinterpret_cast<int *>(red + bd.red_floats + 4 * 32 * 64) + wave * (32 * kStRow);
   const int gl_p = lane >> 2, gl_j = lane & 3;   // gather role: pixel of a half tile, lane of its quad
@@ -334,7 +384,11 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
   // out of range and the parked accumulators are 0
   int voff[NP], gc_voff = kOob;
   int voffc[NC];   // CL: byte offsets of the 2^ND corners of the lane's pixel in xt (+ 16 * kh)
-  float w[NC], dw[ND][NC], mg = 0.f;
+  // What finish_tap needs of the sampling state, in factored form (round 5: 13 registers instead of the 2^ND weights
+  // and ND x 2^ND derivative weights, 40 in 3-D): per outer axis the low / high weight and derivative factor, and for
+  // the last axis the factors of the pair's two elements (make_pairs_f: a clamped side collapses onto one column)
+  struct Fac { float ol[ND - 1], oh[ND - 1], osl[ND - 1], osh[ND - 1], xw, yw, xs, ys; } fac;
+  float mg = 0.f;
   float S[NC];
   float delta_n[ND], m_n = 1.f;   // raw offset / mask of the unit whose K loop is running
   // NCHW drain: elements of the corner pairs that come along with a wanted neighbour but that the reference never reads
@@ -351,13 +405,12 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
 #pragma unroll
   for (int ci = 0; ci < NC; ++ci) voffc[ci] = kOob;
 #pragma unroll
-  for (int ci = 0; ci < NC; ++ci) { S[ci] = 0.f; w[ci] = 0.f; }
+  for (int ci = 0; ci < NC; ++ci) S[ci] = 0.f;
 #pragma unroll
-  for (int a = 0; a < ND; ++a) {
-    delta_n[a] = 0.f;
+  for (int a = 0; a < ND; ++a) delta_n[a] = 0.f;
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) dw[a][ci] = 0.f;
-  }
+  for (int a = 0; a < ND - 1; ++a) fac.ol[a] = fac.oh[a] = fac.osl[a] = fac.osh[a] = 0.f;
+  fac.xw = fac.yw = fac.xs = fac.ys = 0.f;
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -395,7 +448,7 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       for (int pi = 0; pi < NP; ++pi)
         if (ax[pi] != 0.f || ay[pi] != 0.f) atomicAdd(cseg + aidx[pi], 1);
     }
-    if (count && kh == 0) {
+    if (!COLS && count && kh == 0) {
       // ... and writes the tap-table entry GEMM-2 reads for (dgp, tapp, pixel): byte offsets of
       // the corner pairs (image base folded in) + the 2^ND weights with the mask folded in
       // (layout: mfma_bwd_weight.hip); pixels of the padded tail get an all-zero entry
@@ -433,17 +486,17 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       }
       voffc[2 * pi] = prx[pi] ? (pp.b * g.S_i + pidx[pi]) * g.C * 4 + 16 * kh : kOob;
       voffc[2 * pi + 1] = pry[pi] ? (pp.b * g.S_i + pidx[pi] + 1) * g.C * 4 + 16 * kh : kOob;
-      w[2 * pi] = px[pi];
-      w[2 * pi + 1] = py[pi];
     }
+    {
+      constexpr int L = ND - 1;
+      const int lc = tc.last_lc, hc = tc.last_lc + tc.delta[L];
+      const int cl = min(lc, g.in_sz[L] - 2);
+      fac.xw = (lc == cl ? tc.wl[L] : 0.f) + (hc == cl ? tc.wh[L] : 0.f);
+      fac.yw = (lc == cl + 1 ? tc.wl[L] : 0.f) + (hc == cl + 1 ? tc.wh[L] : 0.f);
+      fac.xs = (lc == cl ? tc.sl[L] : 0.f) + (hc == cl ? tc.sh[L] : 0.f);
+      fac.ys = (lc == cl + 1 ? tc.sl[L] : 0.f) + (hc == cl + 1 ? tc.sh[L] : 0.f);
 #pragma unroll
-    for (int a = 0; a < ND; ++a) {
-      make_pairs_d<ND, float>(g, tc, a, px, py);
-#pragma unroll
-      for (int pi = 0; pi < NP; ++pi) {
-        dw[a][2 * pi] = px[pi];
-        dw[a][2 * pi + 1] = py[pi];
-      }
+      for (int a = 0; a < L; ++a) { fac.ol[a] = tc.wl[a]; fac.oh[a] = tc.wh[a]; fac.osl[a] = tc.sl[a]; fac.osh[a] = tc.sh[a]; }
     }
     gc_voff = pp.live ? ((((pp.b * g.K + tapp) * g.S_o + pp.pix) * g.C) + 4 * kh) * 4 : kOob;
     if (CL && kh == 0) {
@@ -452,11 +505,21 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       for (int c4 = 0; c4 < NC; c4 += 4)
         *reinterpret_cast<int4 *>(st + c4) = make_int4(voffc[c4], voffc[c4 + 1], voffc[c4 + 2], voffc[c4 + 3]);
       st[NC] = gc_voff;
+      if constexpr (COLS) {
+        // column row of (tapp, pixel n) in [tap][n][c]; dead pixels and the padded tail are dropped by the bounds check
+        const int n = pp.n0 + wp * 32 + lane;
+        st[NC + 1] = pp.live ? (tapp * bd.Np + n) * g.C * 4 : kOob;
+        float *sw = reinterpret_cast<float *>(st + 2 * NC + 4);
+#pragma unroll
+        for (int c4 = 0; c4 < NC; c4 += 4)
+          *reinterpret_cast<float4 *>(sw + c4) = make_float4(px[c4 / 2] * m_n, py[c4 / 2] * m_n, px[c4 / 2 + 1] * m_n, py[c4 / 2 + 1] * m_n);
+      }
     }
     // S[e] = sum over this lane's channels of grad_col * (element e of the corner pairs).  The
     // corner weights and their derivatives do not depend on the channel, so the drain costs
     // 2^ND FMAs per channel and grad_mask / grad_offset are recovered from S once per tap:
-    //   grad_mask += sum_ci w[ci] S[ci],   grad_offset_a += m * sum_ci dw[a][ci] S[ci].
+    //   grad_mask += sum_ci w[ci] S[ci],   grad_offset_a += m * sum_ci dw[a][ci] S[ci]
+    // with w / dw products of per-axis factors (finish_tap forms them from `fac`).
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) S[ci] = 0.f;
   };
@@ -563,6 +626,25 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
           "s_nop 1"
           : "+v"(s[0]), "+v"(s[1]));
       if (gl_j == 0) *reinterpret_cast<float2 *>(st + NC + 4 + cp * CPS) = make_float2(s[0], s[1]);
+      if constexpr (COLS) {
+        const float2 wq2 = *reinterpret_cast<const float2 *>(st + 2 * NC + 4 + cp * CPS);
+        if (cp == 0) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) colacc[e] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            colacc[4 * k + e] = fmaf(wq2.y, v.f[(4 + k) * 4 + e], fmaf(wq2.x, v.f[k * 4 + e], colacc[4 * k + e]));
+        if (cp == HS - 1) {
+          const int cv = st[NC + 1] + 16 * gl_j;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            buf_store4(r_col, (full || cbase_p + 16 * k + 4 * gl_j < g.C) ? cv + 64 * k : kOob, cbase_p * 4,
+                       colacc[4 * k], colacc[4 * k + 1], colacc[4 * k + 2], colacc[4 * k + 3]);
+        }
+      }
       return;
     }
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
@@ -639,14 +721,38 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
   int grp_lo = (u0 % g.K) % kTapGroup;   // first slot of the current tap group held in `red`
   auto finish_tap = [&](int tapp, int blk, bool flush_ok, bool last) {
     float goff[ND], gm = 0.f;
+    {
+      // element ci = 2 pi + e of the pairs has weight outer(pi) * (e ? yw : xw), outer(pi) = product over the outer
+      // axes of the high / low factor (bit (ND-2-a) of pi); the derivative along axis a swaps that axis' factor
+      constexpr int L = ND - 1;
+      float Tw[NP], Ts[NP];
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) gm = fmaf(w[ci], S[ci], gm);
+      for (int pi = 0; pi < NP; ++pi) {
+        Tw[pi] = fmaf(fac.xw, S[2 * pi], fac.yw * S[2 * pi + 1]);
+        Ts[pi] = fmaf(fac.xs, S[2 * pi], fac.ys * S[2 * pi + 1]);
+      }
 #pragma unroll
-    for (int a = 0; a < ND; ++a) {
-      goff[a] = 0.f;
+      for (int a = 0; a < ND; ++a) goff[a] = 0.f;
 #pragma unroll
-      for (int ci = 0; ci < NC; ++ci) goff[a] = fmaf(dw[a][ci], S[ci], goff[a]);
-      goff[a] *= mg;
+      for (int pi = 0; pi < NP; ++pi) {
+        float ow = 1.f;
+#pragma unroll
+        for (int a = 0; a < L; ++a) ow *= ((pi >> (L - 1 - a)) & 1) ? fac.oh[a] : fac.ol[a];
+        gm = fmaf(ow, Tw[pi], gm);
+        goff[L] = fmaf(ow, Ts[pi], goff[L]);
+#pragma unroll
+        for (int a = 0; a < L; ++a) {
+          float od = 1.f;
+#pragma unroll
+          for (int a2 = 0; a2 < L; ++a2) {
+            const bool hi = (pi >> (L - 1 - a2)) & 1;
+            od *= (a2 == a) ? (hi ? fac.osh[a2] : fac.osl[a2]) : (hi ? fac.oh[a2] : fac.ol[a2]);
+          }
+          goff[a] = fmaf(od, Tw[pi], goff[a]);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < ND; ++a) goff[a] *= mg;
     }
     // reduce over channels: the two half-waves here, the blocks of a group at the flush
     if (!CL) {   // (CL: both half-waves already hold the sums over all 64 channels)
@@ -1243,6 +1349,26 @@ int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq
   return check_launch("pack_wq");
 }
 
+int bwd_prep_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, int *cnt, const float *x,
+                 float *xt, hipStream_t stream) {
+  const int64_t pack_total = (int64_t)g.K * bd.ochunks * bd.cblks_q * 2 * 64;
+  const int64_t cnt_n = (int64_t)g.B * g.DG * bd.S_e;
+  int nb_pack = grid_for(pack_total), nb_zero = grid_for(cnt_n);
+  if (nb_pack > 512) nb_pack = 512;
+  if (nb_zero > 256) nb_zero = 256;
+  const int qtiles = (g.S_i + 31) / 32, ctiles = g.C / 32;
+  const int64_t nb_t = xt ? (int64_t)qtiles * ctiles * g.B : 0;
+  if (nb_t + nb_pack + nb_zero > 0x7fffffff) {   // (not with tensors below 2 GiB; fall back to the three launches)
+    int rc = pack_wq_f32(g, bd, weight, wq, stream);
+    if (!rc) rc = csr_zero_f32(g, bd, cnt, stream);
+    if (!rc && xt) rc = nchw_to_nhwc_f32(g, x, xt, stream);
+    return rc;
+  }
+  hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)(nb_pack + nb_zero + nb_t)), dim3(256), 0, stream, g, bd.ochunks,
+                     bd.cblks_q, weight, wq, cnt, cnt_n, x, xt, nb_pack, nb_zero, qtiles, ctiles);
+  return check_launch("bwd_prep");
+}
+
 int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1261,22 +1387,22 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
   const int passes = bd.cblks_q / (2 * bd.waves_c);
   const size_t red = (size_t)bd.red_floats;
   // channels-last drain: parked accumulators [4 waves][32][64] + state rows [4 waves][32][2^nd * 2 + 4]
-  const size_t cl = bd.cl_drain ? (size_t)4 * 32 * 64 + (size_t)4 * 32 * (2 * (1 << g.nd) + 4) : 0;
+  const size_t cl = bd.cl_drain ? (size_t)4 * 32 * 64 + (size_t)4 * 32 * (2 * (1 << g.nd) + 4 + (bd.col_rows ? (1 << g.nd) : 0)) : 0;
   return ((size_t)bnp * (bd.ochunks * 16 + 4) + red + cl) * sizeof(float);
 }
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, float *ga, float *bias_part, int *cnt, int *table,
-                      const float *xt, hipStream_t stream) {
+                      const float *xt, float *colbuf, hipStream_t stream) {
   // cnt: per-(image, deformable group, input pixel) counters (zeroed by csr_zero_f32), counted
   // by GEMM-1 (CSR pass 1)
-#define LAUNCH_BD_(ND, MOD, WC, QPQ, CL)                                                            \
+#define LAUNCH_BD_(ND, MOD, WC, QPQ, CL, COLS)                                                      \
   do {                                                                                          \
     const int bnp = 32 * (4 / WC);                                                              \
     const int ntiles = (g.N + bnp - 1) / bnp;                                                   \
     const size_t lds = bwd_data_lds_bytes(g, bd);                                               \
     if (lds > 64 * 1024) {                                                                      \
-      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, \
+      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, COLS>, \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; } \
     }                                                                                           \
@@ -1290,7 +1416,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
     if (occ_q == 0 || occ_lds != lds) {   /* (unsynchronised: a race only mis-sizes one launch's rounds) */ \
       int nq = 0;                                                                               \
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                       \
-          &nq, (const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, 256, lds);       \
+          &nq, (const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, COLS>, 256, lds);       \
       (void)hipGetLastError();                                                                  \
       occ_q = nq > 0 ? nq : (lds * 2 <= 160 * 1024 ? 2 : 1);                                    \
       occ_lds = lds;                                                                            \
@@ -1300,19 +1426,23 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
     static const int tpw_env = getenv("MDCONV_BD_TPW") ? atoi(getenv("MDCONV_BD_TPW")) : 2;     \
     const int tpw = tpw_env > 0 ? tpw_env : 1;   /* whole tiles per workgroup of the full rounds */ \
     const int n_full = ntiles / (slots * tpw) * slots;                                          \
+    static const bool debug_plan = getenv("MDCONV_DEBUG_PLAN") != nullptr;                      \
+    if (debug_plan)                                                                             \
+      fprintf(stderr, "[mdconv] GEMM-1 plan: %d tiles, %zu B LDS, %d resident per CU, col rows %d\n", ntiles, lds, occ_q, bd.col_rows); \
     const int n_tail = (int)std::min<int64_t>((int64_t)(ntiles - n_full * tpw) * g.K, slots);   \
-    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>), dim3(n_full + n_tail), \
+    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, COLS>), dim3(n_full + n_tail), \
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
-                       (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, table, xt,        \
+                       (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, table, xt, colbuf, \
                        ntiles, n_full, n_tail, tpw);                                            \
   } while (0)
 /* channels-last drain only where it pays (3-D) */                                                \
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
   do {                                                                                          \
-    if (xt != nullptr && bd.cl_drain) LAUNCH_BD_(ND, MOD, WC, QPQ, true);                       \
-    else LAUNCH_BD_(ND, MOD, WC, QPQ, false);                                                   \
+    if (ND == 3 && QPQ == 0 && xt != nullptr && bd.cl_drain && bd.col_rows) LAUNCH_BD_(ND, MOD, WC, (ND == 3 ? QPQ : 0), true, (ND == 3)); \
+    else if (xt != nullptr && bd.cl_drain) LAUNCH_BD_(ND, MOD, WC, QPQ, true, false);           \
+    else LAUNCH_BD_(ND, MOD, WC, QPQ, false, false);                                            \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \

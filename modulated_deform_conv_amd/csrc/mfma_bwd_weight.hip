@@ -339,17 +339,23 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_weight_kernel, dim3(grid_for((int64_t)g.K * g.O * g.Cg)), dim3(256), 0,
                      stream, g, bd, part, (float *)t.grad_weight);
-  if ((rc = check_launch("reduce_weight"))) return rc;
-  if (g.with_bias) {
-    // the split-K partials are consumed by now: `part` doubles as scratch for the stage values
-    hipLaunchKernelGGL(grad_bias_stage1_kernel, dim3((g.O + 63) / 64, kBiasSlices), dim3(256), 0,
-                       stream, g, bd.bias_tiles, bias_part, part);
-    if ((rc = check_launch("grad_bias_stage1"))) return rc;
-    hipLaunchKernelGGL(grad_bias_final_kernel, dim3((g.O + 255) / 256), dim3(256), 0, stream, g, part,
-                       (float *)t.grad_bias);
-    rc = check_launch("grad_bias_final");
-  }
-  return rc;
+  return check_launch("reduce_weight");
+}
+
+// grad_bias: its inputs (GEMM-1's per-tile partial sums) are ready before GEMM-2 starts, so the caller runs it
+// beside GEMM-2 on the forked stream instead of behind the split-K reduction (two launches and their gaps off the
+// critical path); own scratch for the stage values (it used to borrow GEMM-2's partial buffer)
+size_t grad_bias_stage_bytes(const Geom &g) { return (size_t)kBiasSlices * g.O * sizeof(float); }
+
+int grad_bias_f32(const Geom &g, const BwdDims &bd, const float *bias_part, float *stage, float *grad_bias,
+                  hipStream_t stream) {
+  if (!g.with_bias) return MDCONV_OK;
+  hipLaunchKernelGGL(grad_bias_stage1_kernel, dim3((g.O + 63) / 64, kBiasSlices), dim3(256), 0, stream, g,
+                     bd.bias_tiles, bias_part, stage);
+  int rc = check_launch("grad_bias_stage1");
+  if (rc) return rc;
+  hipLaunchKernelGGL(grad_bias_final_kernel, dim3((g.O + 255) / 256), dim3(256), 0, stream, g, stage, grad_bias);
+  return check_launch("grad_bias_final");
 }
 
 }  // namespace mdconv

@@ -34,16 +34,7 @@ constexpr int kSlab = 64;   // channels per LDS slab
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(int C, int S, const float *__restrict__ x,
                                                            float *__restrict__ xt) {
   __shared__ float t[32][33];
-  const int b = blockIdx.z, c0 = blockIdx.y * 32, q0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
-  const float *src = x + ((size_t)b * C + c0) * S;
-  float *dst = xt + ((size_t)b * S + q0) * C + c0;
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) t[r][tx] = (q0 + tx < S) ? src[(size_t)r * S + q0 + tx] : 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int r = ty; r < 32; r += 8)
-    if (q0 + r < S) dst[(size_t)r * C + tx] = t[tx][r];
+  nchw_to_nhwc_tile(t, C, S, x, xt, blockIdx.z, blockIdx.y * 32, blockIdx.x * 32);
 }
 
 template <int ND, bool MOD, int BM, int BN, int WM>

@@ -127,6 +127,12 @@ BwdDims bwd_dims(const Geom &g) {
   static const int bw_tile_env = getenv("MDCONV_BW_TILE") ? atoi(getenv("MDCONV_BW_TILE")) : 0;
   if (bw_tile_env == 1 && g.O <= 64) bd.wtile = 1;
   if (bd.cl) bd.wtile = g.O <= 64 ? 1 : (g.O <= 128 ? 2 : 3);
+  // 3-D, narrow tiles: GEMM-1's channels-last drain also writes the column rows and GEMM-2 is a dense product over
+  // them -- one gather pass over xt less (mfma_bwd_data.hip COLS; MDCONV_BW_COLS=0: GEMM-2 re-gathers, the round-4 way)
+  {
+    static const int cols_env = getenv("MDCONV_BW_COLS") ? atoi(getenv("MDCONV_BW_COLS")) : 1;
+    bd.col_rows = (cols_env && g.nd == 3 && bd.cl && bd.wtile >= 1 && bd.wtile <= 2 && bwd_weight_slab_enabled()) ? 1 : 0;
+  }
   const int rm = bd.cl ? (bd.wtile == 1 ? 64 : (bd.wtile == 2 ? 128 : 256)) : (bd.wtile ? 64 : 256);
   const int cn = bd.cl ? 64 : (bd.wtile ? 64 : 32);
   bd.OgpB = (g.O + rm - 1) / rm * rm;
@@ -142,7 +148,7 @@ BwdDims bwd_dims(const Geom &g) {
   // reaches 0.8+.  slots = CUs x resident workgroups of the instance that will run (hipOccupancy).
   // MDCONV_BW_SPLITS overrides (experiments).
   const bool padn = bd.Np != g.N;
-  const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile)
+  const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile, bd.col_rows != 0)
                         : mfma_bwd_weight_occupancy(g.nd, padn, bd.wtile);
   // ... minus one per CU when the grad_input gather runs beside this kernel on the forked stream: a full round of
   // 164-register workgroups leaves the gather no wave slot until the round retires, and the two tails then run one
@@ -190,6 +196,7 @@ BwdDims bwd_dims(const Geom &g) {
       bd.cl_drain = 0;
       size_red();
     }
+    if (!bd.cl_drain) bd.col_rows = 0;   // (3-D shapes always drain channels-last; kept consistent for forced settings)
   }
   const int nc = 1 << g.nd;
   size_t off = 0;
@@ -211,6 +218,8 @@ BwdDims bwd_dims(const Geom &g) {
   static const int c2i_env = getenv("MDCONV_C2I3D") ? atoi(getenv("MDCONV_C2I3D")) : 2;
   bd.two_pass = bd.sample_keyed && c2i_env >= 2 ? 1 : 0;
   bd.off_sums = off; off += bd.two_pass ? align_up(col2im3d_sums_bytes(g)) : 0;
+  bd.off_bstage = off; off += g.with_bias ? align_up(grad_bias_stage_bytes(g)) : 0;
+  bd.off_col = off; off += bd.col_rows ? align_up((size_t)g.K * bd.Np * g.C * sizeof(float)) : 0;
   bd.off_end = off;
   return bd;
 }
@@ -275,7 +284,7 @@ bool make_plan(const Geom &g, int dtype, bool backward, Plan *p) {
     const size_t per_ga = (size_t)g.S_o * b1.OgpB * 4;
     const size_t per_tab = (size_t)g.DG * g.K * g.S_o * 2 * (1 << g.nd) * 4;
     const size_t per_ent = (size_t)g.DG * g.K * g.S_o * 32;   // 2 pair entries (2-D) or 1 sample entry (3-D)
-    if (per_col > per) per = per_col;
+    if (per_col + 32 * (size_t)g.K * g.C * 4 > per) per = per_col + 32 * (size_t)g.K * g.C * 4;   // column rows: N rounded up to 32
     if (per_ga > per) per = per_ga;
     if (per_tab > per) per = per_tab;
     if (per_ent > per) per = per_ent;
@@ -354,7 +363,7 @@ int narrow(int dtype, const float *src, void *dst, int64_t n, bool accum, hipStr
 // grad_input gather (CSR build + col2im, HBM-bound) needs GEMM-1's grad_col and counters only, GEMM-2
 // (matrix-bound) needs GEMM-1's packed grad_out and tap table only.  One side stream and two events
 // per (device, caller stream), created on first use and kept (bounded like the weights-ready events).
-struct Fork { hipStream_t side; hipEvent_t fork, join; };
+struct Fork { hipStream_t side; hipEvent_t fork, join, bias; };
 std::mutex g_fork_mu;
 std::vector<std::pair<std::pair<int, hipStream_t>, Fork>> g_forks;
 bool get_fork(hipStream_t stream, Fork *out) {
@@ -377,7 +386,8 @@ bool get_fork(hipStream_t stream, Fork *out) {
   const int prio = prio_env < 0 ? greatest : (prio_env > 0 ? least : 0);
   if (hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, prio) != hipSuccess) return false;
   if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&f.bias, hipEventDisableTiming) != hipSuccess)
     return false;
   g_forks.push_back({{dev, stream}, f});
   *out = f;
@@ -414,19 +424,38 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   int *cnt = (int *)(base + bd.off_cnt), *rowptr = (int *)(base + bd.off_rowptr);
   void *entries = base + bd.off_entries;
   int rc;
-  if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
-  if ((rc = csr_zero_f32(g, bd, cnt, stream))) return rc;
   float *bias_part = g.with_bias ? (float *)(base + bd.off_bias) : nullptr;
+  float *bstage = g.with_bias ? (float *)(base + bd.off_bstage) : nullptr;
   // channels-last copy of the input for the 3-D gathers of GEMM-1's drain and of GEMM-2
   float *xt = bd.cl ? (float *)(base + bd.off_xt) : nullptr;
-  if (bd.cl && (rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream))) return rc;
+  // pack_wq, counter clearing and the layout pass: one launch (MDCONV_BWD_PREP=0: three, the round-4 sequence)
+  static const int prep_env = getenv("MDCONV_BWD_PREP") ? atoi(getenv("MDCONV_BWD_PREP")) : 1;
+  if (prep_env) {
+    if ((rc = bwd_prep_f32(g, bd, (const float *)t.weight, wq, cnt, (const float *)t.input, xt, stream))) return rc;
+  } else {
+    if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
+    if ((rc = csr_zero_f32(g, bd, cnt, stream))) return rc;
+    if (bd.cl && (rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream))) return rc;
+  }
   profile_mark(1, true, stream, "mfma_bwd_data_kernel");
-  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, stream);
+  float *colbuf = bd.col_rows ? (float *)(base + bd.off_col) : nullptr;
+  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, colbuf, stream);
   profile_mark(1, false, stream);
   if (rc) return rc;
   Fork fk;
   const bool fork = bwd_fork_enabled() && get_fork(stream, &fk);
   hipStream_t gs = stream;   // stream of the grad_input gather
+  // GEMM-2 + split-K reduction; grad_bias behind them unless the forked stream already took it
+  auto gemm2 = [&](bool bias_here) {
+    int r = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, bd.col_rows ? colbuf : xt, stream);
+    if (!r && bias_here) r = grad_bias_f32(g, bd, bias_part, bstage, (float *)t.grad_bias, stream);
+    if (!r && !bias_here && g.with_bias && hipStreamWaitEvent(stream, fk.bias, 0) != hipSuccess) {
+      set_error("backward fork failed");
+      r = MDCONV_ELAUNCH;
+    }
+    if (!r && weights_final) r = record_weight_ready(stream);
+    return r;
+  };
   if (fork) {
     if (hipEventRecord(fk.fork, stream) != hipSuccess || hipStreamWaitEvent(fk.side, fk.fork, 0) != hipSuccess) {
       set_error("backward fork failed");
@@ -434,15 +463,16 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
     }
     gs = fk.side;
   } else {
-    if ((rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream))) return rc;
-    if (weights_final && (rc = record_weight_ready(stream))) return rc;
+    if ((rc = gemm2(true))) return rc;
   }
   const bool gemm2_first = fork && bwd_fork_mode() == 2;   // (experiment: GEMM-2 enqueued before the gather)
   rc = MDCONV_OK;
-  if (gemm2_first) {
-    rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream);
-    if (!rc && weights_final) rc = record_weight_ready(stream);
+  // forked: grad_bias first on the side stream (beside GEMM-2, off the critical path), its event for the caller's stream
+  if (fork && g.with_bias) {
+    rc = grad_bias_f32(g, bd, bias_part, bstage, (float *)t.grad_bias, gs);
+    if (!rc && hipEventRecord(fk.bias, gs) != hipSuccess) { set_error("backward fork failed"); rc = MDCONV_ELAUNCH; }
   }
+  if (!rc && gemm2_first) rc = gemm2(false);
   if (!rc) rc = csr_build_f32(g, bd, t, cnt, rowptr, entries, gs);
   if (!rc) {
     profile_mark(3, true, gs, bd.sample_keyed ? (bd.two_pass ? "col2im3d_sums_kernel" : "col2im3d_kernel") : "col2im_gather_kernel");
@@ -450,10 +480,7 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
     profile_mark(3, false, gs);
   }
   if (fork) {
-    if (!rc && !gemm2_first) {
-      rc = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream);
-      if (!rc && weights_final) rc = record_weight_ready(stream);
-    }
+    if (!rc && !gemm2_first) rc = gemm2(false);
     // join on every path after the fork (error returns included): the side stream must not outlive the call
     if ((hipEventRecord(fk.join, fk.side) != hipSuccess || hipStreamWaitEvent(stream, fk.join, 0) != hipSuccess) && !rc) {
       set_error("backward join failed");

@@ -87,10 +87,27 @@ struct BwdDims {
   int sample_keyed;     // scatter lists: 1 = one entry per SAMPLE (3-D, mfma_csr3d.hip), 0 = per corner pair
   int S_e;              // list heads per (image, deformable group): anchor space (3-D) or S_i
   size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
-      off_xt, off_sums, off_end;   // off_sums: per-anchor partial sums of the two-pass 3-D gather (0 bytes otherwise)
+      off_xt, off_sums, off_bstage, off_col, off_end;   // off_sums: per-anchor partial sums of the two-pass 3-D gather (0 bytes otherwise)
+  int col_rows;         // 3-D, channels-last: GEMM-1's drain writes the column rows [tap][n][c], GEMM-2 is a dense product
   int two_pass;         // 3-D grad_input gather: 1 = per-anchor partial sums + stencil (mfma_csr3d.hip), 0 = block walk
 };
 BwdDims bwd_dims(const Geom &g);
+
+#ifdef __HIPCC__
+// xt[b][q0 + r][c0 + tx] = x[b][c0 + r][q0 + tx] for one 32 x 32 tile through LDS (256 threads; C is a multiple of 32)
+__device__ __forceinline__ void nchw_to_nhwc_tile(float (*t)[33], int C, int S, const float *__restrict__ x,
+                                                  float *__restrict__ xt, int b, int c0, int q0) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
+  const float *src = x + ((size_t)b * C + c0) * S;
+  float *dst = xt + ((size_t)b * S + q0) * C + c0;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) t[r][tx] = (q0 + tx < S) ? src[(size_t)r * S + q0 + tx] : 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (q0 + r < S) dst[(size_t)r * C + tx] = t[tx][r];
+}
+#endif
 
 // ---- internal entry points (fp32) ----
 // wp : forward A operand in MFMA-fragment order, so a wave reads its 32x8 fragment with ONE fully
@@ -111,23 +128,33 @@ bool fwd_channels_last(const Geom &g);
 size_t fwd_cl_bytes(const Geom &g);
 int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
                         float *xt, hipStream_t stream);
+// xt: the channels-last input copy, or (bd.col_rows) the column rows GEMM-1's drain wrote
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, const float *xt,
                         hipStream_t stream);
 int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt, const float *ga,
                               const int *table, float *part, hipStream_t stream);
+bool bwd_weight_slab_enabled();   // the 64-pixel-slab GEMM-2 of the narrow tiles is on (MDCONV_BW_SLAB)
 // resident workgroups per CU of the GEMM-2 instance a shape selects (hipOccupancy, cached); device_cus() = CUs of
 // the current device (256 on MI355X; the same figure without a device, for host-only callers)
-int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile);
+int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile, bool dense);
 int mfma_bwd_weight_occupancy(int nd, bool padn, int wtile);
 int device_cus();
 bool bwd_channels_last(const Geom &g);
 int nchw_to_nhwc_f32(const Geom &g, const float *x, float *xt, hipStream_t stream);
 int pack_wq_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, hipStream_t stream);
+// pack_wq + counter clearing + (xt != nullptr) the channels-last input copy as ONE launch: three dependent 5-40 us
+// kernels in front of GEMM-1 cost two launch gaps of 6-22 us on top of their own time (kernel trace, round 4)
+int bwd_prep_f32(const Geom &g, const BwdDims &bd, const float *weight, float *wq, int *cnt, const float *x,
+                 float *xt, hipStream_t stream);
+// grad_bias from the per-tile partial sums GEMM-1 left (two ordered stages; `stage` = grad_bias_stage_bytes scratch)
+size_t grad_bias_stage_bytes(const Geom &g);
+int grad_bias_f32(const Geom &g, const BwdDims &bd, const float *bias_part, float *stage, float *grad_bias,
+                  hipStream_t stream);
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, float *ga, float *bias_part, int *cnt, int *table,
-                      const float *xt, hipStream_t stream);
+                      const float *xt, float *colbuf, hipStream_t stream);
 int csr_zero_f32(const Geom &g, const BwdDims &bd, int *cnt, hipStream_t stream);
 int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, int *rowptr,
                   void *entries, hipStream_t stream);
