@@ -158,19 +158,13 @@ __device__ unsigned long long g_b1_timing[12];
 #ifndef B1_MINWAVES
 #define B1_MINWAVES 2
 #endif
-// COLS (round 5; channels-last drain only): the drain also forms the COLUMN rows  col[tap][n][c] = mask * sum over the
-// corners of w * x  from the corner values it has gathered anyway (+32 FMAs per lane and batch, 16 accumulators carried
-// over the 4 corner-pair batches of a half tile) and streams them to `colbuf`; GEMM-2 then is a DENSE product over
-// those rows (mfma_bwd_weight_cl.hip) instead of a third gather pass over xt -- in 3-D, where 8 corners of 256 bytes
-// per (pixel, tap) make every gathering kernel texture-path bound.  The tap table GEMM-2 used to read is not written.
-template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL, bool COLS = false>
+template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL>
 __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
     float *__restrict__ ga, float *__restrict__ bias_part, int *__restrict__ cnt,
-    int *__restrict__ table, const float *__restrict__ xt, float *__restrict__ colbuf, int ntiles, int n_full, int n_tail, int tpw) {
-  static_assert(!COLS || CL, "column rows come out of the channels-last drain");
+    int *__restrict__ table, const float *__restrict__ xt, int ntiles, int n_full, int n_tail, int tpw) {
   constexpr int NC = 1 << ND, NP = NC / 2;
   constexpr int MB = 2;
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -221,16 +215,13 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
   const rsrc_t r_in = make_rsrc(CL ? xt : input, (size_t)g.B * g.C * g.S_i * 4);
   const rsrc_t r_wq = make_rsrc(wq, (size_t)g.K * T_o * chunk_bytes);
   const rsrc_t r_gc = make_rsrc(gcol, (size_t)g.B * g.C * g.K * g.S_o * 4);
-  const rsrc_t r_col = make_rsrc(COLS ? colbuf : gcol, COLS ? (size_t)g.K * bd.Np * g.C * 4 : 0);   // [tap][n][c]
-  float colacc[COLS ? 16 : 1];
   const int a_lane = lane * 16;
   const float *Bb = Gs + (wp * 32 + (lane & 31)) * gpitch + 4 * kh;
   // CL drain (line-wide gathers, see `gather`): per wave a parked-accumulator tile Pk[32][64]
   // ([pixel][channel], 16-byte pieces XOR-swizzled by the pixel so that both the accumulator-layout
   // writes and the gather-layout reads are bank-conflict free without padding), and per pixel a
   // state row St[kStRow]: 2^ND corner byte offsets into xt, the grad_col row offset, 2^ND corner sums
-  // (COLS: + the 2^ND corner weights with the mask folded in; slot NC + 1 = byte offset of the pixel's column row)
-  constexpr int kStRow = 2 * NC + 4 + (COLS ? NC : 0);
+  constexpr int kStRow = 2 * NC + 4;
   float *Pk = red + bd.red_floats + wave * (32 * 64);
   int *St = reinterpret_cast<int *>(red + bd.red_floats + 4 * 32 * 64) + wave * (32 * kStRow);
   const int gl_p = lane >> 2, gl_j = lane & 3;   // gather role: pixel of a half tile, lane of its quad
@@ -448,7 +439,7 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       for (int pi = 0; pi < NP; ++pi)
         if (ax[pi] != 0.f || ay[pi] != 0.f) atomicAdd(cseg + aidx[pi], 1);
     }
-    if (!COLS && count && kh == 0) {
+    if (count && kh == 0) {
       // ... and writes the tap-table entry GEMM-2 reads for (dgp, tapp, pixel): byte offsets of
       // the corner pairs (image base folded in) + the 2^ND weights with the mask folded in
       // (layout: mfma_bwd_weight.hip); pixels of the padded tail get an all-zero entry
@@ -505,15 +496,6 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       for (int c4 = 0; c4 < NC; c4 += 4)
         *reinterpret_cast<int4 *>(st + c4) = make_int4(voffc[c4], voffc[c4 + 1], voffc[c4 + 2], voffc[c4 + 3]);
       st[NC] = gc_voff;
-      if constexpr (COLS) {
-        // column row of (tapp, pixel n) in [tap][n][c]; dead pixels and the padded tail are dropped by the bounds check
-        const int n = pp.n0 + wp * 32 + lane;
-        st[NC + 1] = pp.live ? (tapp * bd.Np + n) * g.C * 4 : kOob;
-        float *sw = reinterpret_cast<float *>(st + 2 * NC + 4);
-#pragma unroll
-        for (int c4 = 0; c4 < NC; c4 += 4)
-          *reinterpret_cast<float4 *>(sw + c4) = make_float4(px[c4 / 2] * m_n, py[c4 / 2] * m_n, px[c4 / 2 + 1] * m_n, py[c4 / 2 + 1] * m_n);
-      }
     }
     // S[e] = sum over this lane's channels of grad_col * (element e of the corner pairs).  The
     // corner weights and their derivatives do not depend on the channel, so the drain costs
@@ -626,25 +608,6 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
           "s_nop 1"
           : "+v"(s[0]), "+v"(s[1]));
       if (gl_j == 0) *reinterpret_cast<float2 *>(st + NC + 4 + cp * CPS) = make_float2(s[0], s[1]);
-      if constexpr (COLS) {
-        const float2 wq2 = *reinterpret_cast<const float2 *>(st + 2 * NC + 4 + cp * CPS);
-        if (cp == 0) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) colacc[e] = 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            colacc[4 * k + e] = fmaf(wq2.y, v.f[(4 + k) * 4 + e], fmaf(wq2.x, v.f[k * 4 + e], colacc[4 * k + e]));
-        if (cp == HS - 1) {
-          const int cv = st[NC + 1] + 16 * gl_j;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            buf_store4(r_col, (full || cbase_p + 16 * k + 4 * gl_j < g.C) ? cv + 64 * k : kOob, cbase_p * 4,
-                       colacc[4 * k], colacc[4 * k + 1], colacc[4 * k + 2], colacc[4 * k + 3]);
-        }
-      }
       return;
     }
     const int mb = (q * RB) / 16, r0 = (q * RB) % 16;
@@ -1387,22 +1350,22 @@ size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd) {
   const int passes = bd.cblks_q / (2 * bd.waves_c);
   const size_t red = (size_t)bd.red_floats;
   // channels-last drain: parked accumulators [4 waves][32][64] + state rows [4 waves][32][2^nd * 2 + 4]
-  const size_t cl = bd.cl_drain ? (size_t)4 * 32 * 64 + (size_t)4 * 32 * (2 * (1 << g.nd) + 4 + (bd.col_rows ? (1 << g.nd) : 0)) : 0;
+  const size_t cl = bd.cl_drain ? (size_t)4 * 32 * 64 + (size_t)4 * 32 * (2 * (1 << g.nd) + 4) : 0;
   return ((size_t)bnp * (bd.ochunks * 16 + 4) + red + cl) * sizeof(float);
 }
 
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, float *ga, float *bias_part, int *cnt, int *table,
-                      const float *xt, float *colbuf, hipStream_t stream) {
+                      const float *xt, hipStream_t stream) {
   // cnt: per-(image, deformable group, input pixel) counters (zeroed by csr_zero_f32), counted
   // by GEMM-1 (CSR pass 1)
-#define LAUNCH_BD_(ND, MOD, WC, QPQ, CL, COLS)                                                      \
+#define LAUNCH_BD_(ND, MOD, WC, QPQ, CL)                                                            \
   do {                                                                                          \
     const int bnp = 32 * (4 / WC);                                                              \
     const int ntiles = (g.N + bnp - 1) / bnp;                                                   \
     const size_t lds = bwd_data_lds_bytes(g, bd);                                               \
     if (lds > 64 * 1024) {                                                                      \
-      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, COLS>, \
+      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; } \
     }                                                                                           \
@@ -1416,7 +1379,7 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
     if (occ_q == 0 || occ_lds != lds) {   /* (unsynchronised: a race only mis-sizes one launch's rounds) */ \
       int nq = 0;                                                                               \
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                       \
-          &nq, (const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, COLS>, 256, lds);       \
+          &nq, (const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, 256, lds);       \
       (void)hipGetLastError();                                                                  \
       occ_q = nq > 0 ? nq : (lds * 2 <= 160 * 1024 ? 2 : 1);                                    \
       occ_lds = lds;                                                                            \
@@ -1428,21 +1391,20 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
     const int n_full = ntiles / (slots * tpw) * slots;                                          \
     static const bool debug_plan = getenv("MDCONV_DEBUG_PLAN") != nullptr;                      \
     if (debug_plan)                                                                             \
-      fprintf(stderr, "[mdconv] GEMM-1 plan: %d tiles, %zu B LDS, %d resident per CU, col rows %d\n", ntiles, lds, occ_q, bd.col_rows); \
+      fprintf(stderr, "[mdconv] GEMM-1 plan: %d tiles, %zu B LDS, %d resident per CU\n", ntiles, lds, occ_q); \
     const int n_tail = (int)std::min<int64_t>((int64_t)(ntiles - n_full * tpw) * g.K, slots);   \
-    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL, COLS>), dim3(n_full + n_tail), \
+    hipLaunchKernelGGL((mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>), dim3(n_full + n_tail), \
                        dim3(256), lds, stream,                                                  \
                        g, bd, (const float *)t.input, (const float *)t.grad_output, wq,         \
                        (const float *)t.offset, (const float *)t.mask, gcol,                    \
-                       (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, table, xt, colbuf, \
+                       (float *)t.grad_offset, (float *)t.grad_mask, ga, bias_part, cnt, table, xt,        \
                        ntiles, n_full, n_tail, tpw);                                            \
   } while (0)
 /* channels-last drain only where it pays (3-D) */                                                \
 #define LAUNCH_BD(ND, MOD, WC, QPQ)                                                             \
   do {                                                                                          \
-    if (ND == 3 && QPQ == 0 && xt != nullptr && bd.cl_drain && bd.col_rows) LAUNCH_BD_(ND, MOD, WC, (ND == 3 ? QPQ : 0), true, (ND == 3)); \
-    else if (xt != nullptr && bd.cl_drain) LAUNCH_BD_(ND, MOD, WC, QPQ, true, false);           \
-    else LAUNCH_BD_(ND, MOD, WC, QPQ, false, false);                                            \
+    if (xt != nullptr && bd.cl_drain) LAUNCH_BD_(ND, MOD, WC, QPQ, true);                       \
+    else LAUNCH_BD_(ND, MOD, WC, QPQ, false);                                                   \
   } while (0)
 #define LAUNCH_BD2(ND, MOD)                                                                     \
   do {                                                                                          \

@@ -249,9 +249,7 @@ __global__ __launch_bounds__(256, 1) void mfma_bwd_weight_cl_kernel(Geom g, BwdD
 // MFMAs of slab t, and the tap-table entries of a slab staged global -> registers -> LDS two slabs ahead
 // (one coalesced 16-byte load per thread) instead of a dependent global load in front of every gather.
 // <MB>: 1 = 64 x 64 tile (C_out <= 64), 2 = 128 x 64 (C_out <= 128); 2 x 2 waves.
-// DENSE: `xt` holds the COLUMN rows col[tap][n][c] that GEMM-1's drain wrote (mfma_bwd_data.hip, COLS): the slab is
-// loaded, not gathered and blended -- one 16-byte load per (pixel, channel quad), no tap table.
-template <int ND, bool PADN, int MB, bool DENSE = false>
+template <int ND, bool PADN, int MB>
 __global__ __launch_bounds__(256) void mfma_bwd_weight_cl64_kernel(Geom g, BwdDims bd,
                                                                    const float *__restrict__ xt,
                                                                    const float *__restrict__ ga,
@@ -286,8 +284,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl64_kernel(Geom g, BwdDi
   const int p_end = min(p_begin + bd.pairs_per_split, pairs_total);
   const int t_begin = 2 * p_begin, t_end = 2 * p_end;   // 16-pixel chunks
 
-  const rsrc_t r_xt = DENSE ? make_rsrc(xt + (size_t)tap * bd.Np * g.C, (size_t)bd.Np * g.C * sizeof(float))
-                            : make_rsrc(xt, (size_t)g.B * g.S_i * g.C * sizeof(float));
+  const rsrc_t r_xt = make_rsrc(xt, (size_t)g.B * g.S_i * g.C * sizeof(float));
   const int slab_bytes = bd.mblks * 2 * 64 * 16;        // packed grad_out of one 16-pixel chunk
   const rsrc_t r_ga = make_rsrc(ga, (size_t)(bd.Np / 16) * slab_bytes);
   const int entry_bytes = SW * 4;
@@ -312,21 +309,14 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl64_kernel(Geom g, BwdDi
 
   // table slab of the 64 pixels from chunk t on: one 16-byte piece per thread (2-D: the first 128 threads)
   auto load_tab = [&](int t) {
-    if (DENSE) return make_float4(0.f, 0.f, 0.f, 0.f);
     const bool on = tid * 16 < SP * entry_bytes;
     return buf_load4(r_tab, on ? tid * 16 : 0x7ffffff0, t * 16 * entry_bytes);
   };
   auto store_tab = [&](const float4 &v, int *Tb) {
-    if (DENSE) return;
     if (tid * 16 < SP * entry_bytes) *reinterpret_cast<float4 *>(Tb + tid * 4) = v;
   };
-  struct Px { float4 v[DENSE ? 1 : NC]; };
-  // DENSE: pixel p of the slab that starts at chunk `tn` is row tn * 16 + p of the tap's column rows
-  auto issue_px = [&](Px &px, const int *Tb, int p, int tn) {
-    if constexpr (DENSE) {
-      px.v[0] = buf_load4(r_xt, (tn * 16 + p) * g.C * 4 + c_voff, 0);   // (rows beyond Np: out of range -> 0)
-      return;
-    }
+  struct Px { float4 v[NC]; };
+  auto issue_px = [&](Px &px, const int *Tb, int p) {
     const int *sp = Tb + p * SW;
     int co[NC];
 #pragma unroll
@@ -338,13 +328,6 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl64_kernel(Geom g, BwdDi
     for (int ci = 0; ci < NC; ++ci) px.v[ci] = buf_load4(r_xt, co[ci] + c_voff, 0);
   };
   auto commit_px = [&](const Px &px, const int *Tb, int p, bool live, float *Bb) {
-    if constexpr (DENSE) {
-      // rows of the padded tail (N <= n < Np) are never written by GEMM-1: whatever the workspace holds must not count
-      const float4 s4 = (!PADN || live) ? px.v[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-      float *d = Bb + p * kPitch + cq * 4;
-      d[0] = s4.x; d[1] = s4.y; d[2] = s4.z; d[3] = s4.w;
-      return;
-    }
     const float *sp = reinterpret_cast<const float *>(Tb + p * SW + NC);
     float w[NC];
 #pragma unroll
@@ -398,7 +381,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl64_kernel(Geom g, BwdDi
     for (int i = 0; i < 4; ++i) {
       if (t_begin + i < t_end) {
         Px px;
-        issue_px(px, Ts, pg + 16 * i, t_begin);
+        issue_px(px, Ts, pg + 16 * i);
         commit_px(px, Ts, pg + 16 * i, (t_begin + i) * 16 + pg < g.N, Bs);
       }
     }
@@ -421,7 +404,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl64_kernel(Geom g, BwdDi
         if (j == 1) load_a(ra0, t + 2);
         if (j == 2) load_a(ra1, t + 3);
         if (j == 3) load_a(ra0, t + 4);
-        if (nxt_on) issue_px(px, Tn, p, t + 4);
+        if (nxt_on) issue_px(px, Tn, p);
         __builtin_amdgcn_sched_barrier(0);
         if (t + j < t_end) {
           if (j & 1) mma(ra1, Bcur + (16 * j) * kPitch);
@@ -473,15 +456,9 @@ bool bwd_weight_slab_enabled() {
 }
 #define MDCONV_CL_INSTANCE(ND, PADN, CALL)                                                                     \
   do {                                                                                                          \
-    if (wtile == 1) {                                                                                           \
-      if (dense) CALL##64(ND, PADN, 1, (ND == 3));                                                              \
-      else if (bw_slab_enabled()) CALL##64(ND, PADN, 1, false);                                                 \
-      else CALL(ND, PADN, 2, 2, 1, 1);                                                                          \
-    } else if (wtile == 2) {                                                                                    \
-      if (dense) CALL##64(ND, PADN, 2, (ND == 3));                                                              \
-      else if (bw_slab_enabled()) CALL##64(ND, PADN, 2, false);                                                 \
-      else CALL(ND, PADN, 2, 2, 2, 1);                                                                          \
-    } else { CALL(ND, PADN, 4, 1, 2, 2); }                                                                      \
+    if (wtile == 1) { if (bw_slab_enabled()) CALL##64(ND, PADN, 1); else CALL(ND, PADN, 2, 2, 1, 1); }          \
+    else if (wtile == 2) { if (bw_slab_enabled()) CALL##64(ND, PADN, 2); else CALL(ND, PADN, 2, 2, 2, 1); }     \
+    else { CALL(ND, PADN, 4, 1, 2, 2); }                                                                        \
   } while (0)
 #define MDCONV_CL_DISPATCH(CALL)                                                                               \
   do {                                                                                                          \
@@ -489,18 +466,17 @@ bool bwd_weight_slab_enabled() {
     else { if (padn) MDCONV_CL_INSTANCE(3, true, CALL); else MDCONV_CL_INSTANCE(3, false, CALL); }              \
   } while (0)
 
-int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile, bool dense) {
-  static int cache[2][2][4][2] = {};
-  if (nd != 3 || wtile < 1 || wtile > 2) dense = false;
-  int &slot = cache[nd == 3][padn][wtile < 0 || wtile > 3 ? 3 : wtile][dense];
+int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile) {
+  static int cache[2][2][4] = {};
+  int &slot = cache[nd == 3][padn][wtile < 0 || wtile > 3 ? 3 : wtile];
   if (slot) return slot;
   int n = 0;
 #define OCC_CL(ND, PADN, WR, WC, MB, NBW)                                                                      \
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                                          \
       &n, reinterpret_cast<const void *>(&mfma_bwd_weight_cl_kernel<ND, PADN, WR, WC, MB, NBW>), 256, 0)
-#define OCC_CL64(ND, PADN, MB, DENSE)                                                                          \
+#define OCC_CL64(ND, PADN, MB)                                                                                 \
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                                          \
-      &n, reinterpret_cast<const void *>(&mfma_bwd_weight_cl64_kernel<ND, PADN, MB, DENSE>), 256, 0)
+      &n, reinterpret_cast<const void *>(&mfma_bwd_weight_cl64_kernel<ND, PADN, MB>), 256, 0)
   MDCONV_CL_DISPATCH(OCC_CL);
 #undef OCC_CL64
 #undef OCC_CL
@@ -515,13 +491,12 @@ int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt,
   const dim3 grid(bd.mtiles * g.K * bd.cblks, bd.splits);
   const bool padn = bd.Np != g.N;
   const int nd = g.nd, wtile = bd.wtile;
-  const bool dense = bd.col_rows != 0;
 #define LAUNCH_CL(ND, PADN, WR, WC, MB, NBW)                                                                   \
   hipLaunchKernelGGL((mfma_bwd_weight_cl_kernel<ND, PADN, WR, WC, MB, NBW>), grid, dim3(256), 0,               \
                      stream, g, bd, xt, ga, table, part)
-#define LAUNCH_CL64(ND, PADN, MB, DENSE)                                                                       \
-  hipLaunchKernelGGL((mfma_bwd_weight_cl64_kernel<ND, PADN, MB, DENSE>), grid, dim3(256), 0, stream, g, bd, xt, \
-                     ga, table, part)
+#define LAUNCH_CL64(ND, PADN, MB)                                                                              \
+  hipLaunchKernelGGL((mfma_bwd_weight_cl64_kernel<ND, PADN, MB>), grid, dim3(256), 0, stream, g, bd, xt, ga,   \
+                     table, part)
   MDCONV_CL_DISPATCH(LAUNCH_CL);
 #undef LAUNCH_CL64
 #undef LAUNCH_CL

@@ -127,12 +127,6 @@ BwdDims bwd_dims(const Geom &g) {
   static const int bw_tile_env = getenv("MDCONV_BW_TILE") ? atoi(getenv("MDCONV_BW_TILE")) : 0;
   if (bw_tile_env == 1 && g.O <= 64) bd.wtile = 1;
   if (bd.cl) bd.wtile = g.O <= 64 ? 1 : (g.O <= 128 ? 2 : 3);
-  // 3-D, narrow tiles: GEMM-1's channels-last drain also writes the column rows and GEMM-2 is a dense product over
-  // them -- one gather pass over xt less (mfma_bwd_data.hip COLS; MDCONV_BW_COLS=0: GEMM-2 re-gathers, the round-4 way)
-  {
-    static const int cols_env = getenv("MDCONV_BW_COLS") ? atoi(getenv("MDCONV_BW_COLS")) : 1;
-    bd.col_rows = (cols_env && g.nd == 3 && bd.cl && bd.wtile >= 1 && bd.wtile <= 2 && bwd_weight_slab_enabled()) ? 1 : 0;
-  }
   const int rm = bd.cl ? (bd.wtile == 1 ? 64 : (bd.wtile == 2 ? 128 : 256)) : (bd.wtile ? 64 : 256);
   const int cn = bd.cl ? 64 : (bd.wtile ? 64 : 32);
   bd.OgpB = (g.O + rm - 1) / rm * rm;
@@ -148,7 +142,7 @@ BwdDims bwd_dims(const Geom &g) {
   // reaches 0.8+.  slots = CUs x resident workgroups of the instance that will run (hipOccupancy).
   // MDCONV_BW_SPLITS overrides (experiments).
   const bool padn = bd.Np != g.N;
-  const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile, bd.col_rows != 0)
+  const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile)
                         : mfma_bwd_weight_occupancy(g.nd, padn, bd.wtile);
   // ... minus one per CU when the grad_input gather runs beside this kernel on the forked stream: a full round of
   // 164-register workgroups leaves the gather no wave slot until the round retires, and the two tails then run one
@@ -196,7 +190,6 @@ BwdDims bwd_dims(const Geom &g) {
       bd.cl_drain = 0;
       size_red();
     }
-    if (!bd.cl_drain) bd.col_rows = 0;   // (3-D shapes always drain channels-last; kept consistent for forced settings)
   }
   const int nc = 1 << g.nd;
   size_t off = 0;
@@ -219,7 +212,6 @@ BwdDims bwd_dims(const Geom &g) {
   bd.two_pass = bd.sample_keyed && c2i_env >= 2 ? 1 : 0;
   bd.off_sums = off; off += bd.two_pass ? align_up(col2im3d_sums_bytes(g)) : 0;
   bd.off_bstage = off; off += g.with_bias ? align_up(grad_bias_stage_bytes(g)) : 0;
-  bd.off_col = off; off += bd.col_rows ? align_up((size_t)g.K * bd.Np * g.C * sizeof(float)) : 0;
   bd.off_end = off;
   return bd;
 }
@@ -284,7 +276,7 @@ bool make_plan(const Geom &g, int dtype, bool backward, Plan *p) {
     const size_t per_ga = (size_t)g.S_o * b1.OgpB * 4;
     const size_t per_tab = (size_t)g.DG * g.K * g.S_o * 2 * (1 << g.nd) * 4;
     const size_t per_ent = (size_t)g.DG * g.K * g.S_o * 32;   // 2 pair entries (2-D) or 1 sample entry (3-D)
-    if (per_col + 32 * (size_t)g.K * g.C * 4 > per) per = per_col + 32 * (size_t)g.K * g.C * 4;   // column rows: N rounded up to 32
+    if (per_col > per) per = per_col;
     if (per_ga > per) per = per_ga;
     if (per_tab > per) per = per_tab;
     if (per_ent > per) per = per_ent;
@@ -438,8 +430,7 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
     if (bd.cl && (rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream))) return rc;
   }
   profile_mark(1, true, stream, "mfma_bwd_data_kernel");
-  float *colbuf = bd.col_rows ? (float *)(base + bd.off_col) : nullptr;
-  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, colbuf, stream);
+  rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, stream);
   profile_mark(1, false, stream);
   if (rc) return rc;
   Fork fk;
@@ -447,7 +438,7 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   hipStream_t gs = stream;   // stream of the grad_input gather
   // GEMM-2 + split-K reduction; grad_bias behind them unless the forked stream already took it
   auto gemm2 = [&](bool bias_here) {
-    int r = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, bd.col_rows ? colbuf : xt, stream);
+    int r = mfma_bwd_weight_f32(g, bd, t, ga, table, part, bias_part, xt, stream);
     if (!r && bias_here) r = grad_bias_f32(g, bd, bias_part, bstage, (float *)t.grad_bias, stream);
     if (!r && !bias_here && g.with_bias && hipStreamWaitEvent(stream, fk.bias, 0) != hipSuccess) {
       set_error("backward fork failed");

@@ -87,8 +87,7 @@ struct BwdDims {
   int sample_keyed;     // scatter lists: 1 = one entry per SAMPLE (3-D, mfma_csr3d.hip), 0 = per corner pair
   int S_e;              // list heads per (image, deformable group): anchor space (3-D) or S_i
   size_t off_wq, off_ga, off_table, off_part, off_gcol, off_cnt, off_rowptr, off_entries, off_bias,
-      off_xt, off_sums, off_bstage, off_col, off_end;   // off_sums: per-anchor partial sums of the two-pass 3-D gather (0 bytes otherwise)
-  int col_rows;         // 3-D, channels-last: GEMM-1's drain writes the column rows [tap][n][c], GEMM-2 is a dense product
+      off_xt, off_sums, off_bstage, off_end;   // off_sums: per-anchor partial sums of the two-pass 3-D gather (0 bytes otherwise)
   int two_pass;         // 3-D grad_input gather: 1 = per-anchor partial sums + stencil (mfma_csr3d.hip), 0 = block walk
 };
 BwdDims bwd_dims(const Geom &g);
@@ -128,7 +127,6 @@ bool fwd_channels_last(const Geom &g);
 size_t fwd_cl_bytes(const Geom &g);
 int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
                         float *xt, hipStream_t stream);
-// xt: the channels-last input copy, or (bd.col_rows) the column rows GEMM-1's drain wrote
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, const float *xt,
                         hipStream_t stream);
@@ -137,7 +135,7 @@ int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt,
 bool bwd_weight_slab_enabled();   // the 64-pixel-slab GEMM-2 of the narrow tiles is on (MDCONV_BW_SLAB)
 // resident workgroups per CU of the GEMM-2 instance a shape selects (hipOccupancy, cached); device_cus() = CUs of
 // the current device (256 on MI355X; the same figure without a device, for host-only callers)
-int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile, bool dense);
+int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile);
 int mfma_bwd_weight_occupancy(int nd, bool padn, int wtile);
 int device_cus();
 bool bwd_channels_last(const Geom &g);
@@ -154,7 +152,7 @@ int grad_bias_f32(const Geom &g, const BwdDims &bd, const float *bias_part, floa
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, float *ga, float *bias_part, int *cnt, int *table,
-                      const float *xt, float *colbuf, hipStream_t stream);
+                      const float *xt, hipStream_t stream);
 int csr_zero_f32(const Geom &g, const BwdDims &bd, int *cnt, hipStream_t stream);
 int csr_build_f32(const Geom &g, const BwdDims &bd, const Tensors &t, int *cnt, int *rowptr,
                   void *entries, hipStream_t stream);
