@@ -400,6 +400,172 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   while (cur_a <= a_last) flush();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass 1 on the matrix cores (round 5).  The partial sums of an anchor window are a small GEMM:
+//     A[(anchor, s)][c] = sum over the window's list entries e of  Wt[(anchor, s)][e] * grad_col[src(e)][c]
+// with Wt sparse -- entry e of anchor a carries px[s] for row (a, s) and py[s] for row (a + 1, s) (the column + 1
+// carry of the VALU kernel above).  M = 32 rows = AW anchors x NS target rows (AW = 16 in 2-D, 8 in 3-D), K = 16
+// entries per step, N = 32 channels per accumulator block: v_mfma_f32_32x32x16 does in one instruction per 16
+// entries and 32 channels what the VALU kernel does with 2 NS x 8 fp32 FMAs per entry and lane, and the per-anchor
+// flush (half of that kernel's instructions at cfg3) becomes ONE contiguous 32-row store per window.
+//   * a wave owns a run of kRunM consecutive anchors = kRunM / AW windows; per window it streams the entries of
+//     anchors [w0 - 1, w0 + AW) (the carry-in anchor's entries were read by the previous window a moment ago: an L2 hit);
+//   * per step: lanes 0-15 fetch one entry each (the next step's entries are requested one step ahead), turn it
+//     into 2 NS weights in the tensors' 16-bit type and drop them into a zeroed wave-private LDS tile Wt[16][40] at
+//     column 4 + NS (anchor - w0) (a margin of 4 columns takes the carry-in anchor, the right margin the carry-out);
+//     all lanes fetch the 16 grad_col rows (cseg / 8 lanes per row, 16 bytes each) into the tile R[16][cseg + 32];
+//     both operands come out of LDS with transposing reads (K-major fragments of row-major tiles, lds_tr2);
+//   * no workgroup barrier anywhere: the tiles are wave-private, a wave reads what it wrote.
+// fp32 accumulation; the weights carry 11 (fp16) / 8 (bf16) significant bits like the rows they multiply.
+constexpr int kRunM = 32;    // anchors per wave
+constexpr int kWtP = 40;     // pitch (16-bit elements) of the weight tile: 4 margin + 32 + up to 4 carry-out columns
+constexpr int kWtM = 4;      // left margin
+
+template <int ND, typename T, int NB>
+__global__ __launch_bounds__(256) void hp_col2im_sums_mfma_kernel(Geom g, HpDims hd, int S_e,
+                                                                  const typename T::Raw *__restrict__ gcol,
+                                                                  const int *__restrict__ rowptr,
+                                                                  const int4 *__restrict__ entries,
+                                                                  typename SumStore<T>::type *__restrict__ sums) {
+  using Raw = typename T::Raw;
+  using Sum = typename SumStore<T>::type;
+  constexpr bool WIDE = sizeof(Sum) == 4;
+  constexpr int L = ND - 1, NS = 1 << L, AW = 32 / NS;
+  constexpr int CS = NB * 32;              // channels that share one list
+  constexpr int PB = CS + 32;              // pitch of the row tile
+  constexpr int LPR = CS / 8;              // lanes per grad_col row
+  constexpr int RPI = 64 / LPR;            // rows per wave-load (NB = 8: 2)
+  constexpr int NLD = 16 / RPI;            // wave-loads per step
+  constexpr int RF = WIDE ? 8 : 16;        // rows of the window per flush pass (RF * CS * sizeof(Sum) = 32 CS bytes)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, kh = lane >> 5, pl = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Raw *Wt = reinterpret_cast<Raw *>(smem + wave * (16 * kWtP * 2 + 16 * PB * 2));   // [16][kWtP]
+  Raw *Rt = Wt + 16 * kWtP;                                                          // [16][PB]; flush staging too
+  const int runs_per_seg = (S_e + kRunM - 1) / kRunM;
+  const int run_id = blockIdx.x * 4 + wave;
+  const int seg = run_id / runs_per_seg;                        // b * DG + dg
+  if (seg >= g.B * g.DG) return;
+  const int a_run = (run_id - seg * runs_per_seg) * kRunM;
+  const int b = seg / g.DG, dg = seg - b * g.DG;
+  const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * hd.Cp, (size_t)g.K * g.S_o * hd.Cp * 2);
+  const int *rp = rowptr + (int64_t)seg * (S_e + 1);
+  const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * (ND == 2 ? 1 : 2);
+  Sum *out = sums + ((int64_t)seg * S_e * NS) * CS;
+  // this lane's piece of a grad_col row in the row role: row (lane / LPR) of a wave-load, 16 bytes at channel 8 (lane % LPR)
+  const int r_row = lane / LPR, r_piece = lane % LPR;
+  const int c_voff = (dg * CS + r_piece * 8) * 2;
+  // zero the weight tile once; every step clears what it wrote
+  for (int i = lane; i < 16 * kWtP / 8; i += 64) reinterpret_cast<U4 *>(Wt)[i] = U4{0, 0, 0, 0};
+
+  // fragment addresses (hp_gemm2.hip): lane i of a 16-lane group addresses row (i >> 2), element quad (i & 3) of its 4 x 16 block
+  const int fr_row = 8 * kh + ((lane & 15) >> 2), fr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  for (int w0 = a_run; w0 < min(a_run + kRunM, S_e); w0 += AW) {
+    const int e_lo = rp[max(w0 - 1, 0)], e_hi = rp[min(w0 + AW, S_e)];
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    // entry of this lane for the step that starts at e0 (lanes 0-15)
+    int4 ea = make_int4(0, 0, 0, 0), eb = make_int4(0, 0, 0, 0);
+    auto fetch_entry = [&](int e0) {
+      const int e = e0 + lane;
+      if (lane < 16 && e < e_hi) {
+        if constexpr (ND == 2) ea = ent[e];
+        else { ea = ent[(int64_t)e * 2]; eb = ent[(int64_t)e * 2 + 1]; }
+      }
+    };
+    fetch_entry(e_lo);
+    for (int e0 = e_lo; e0 < e_hi; e0 += 16) {
+      // ---- weights of this step's entries -> Wt; row index for the row loads ----
+      const bool e_on = lane < 16 && e0 + lane < e_hi;
+      const int src = e_on ? ea.x : -1;
+      int wcol = 0;                                    // column of this entry's first weight
+      if (e_on) {
+        const int anc = ND == 2 ? ea.w : eb.w;
+        wcol = kWtM + NS * (anc - w0);                 // anc in [w0 - 1, w0 + AW): columns [kWtM - NS, kWtM + 32)
+        Raw *wp_ = Wt + lane * kWtP + wcol;
+        if constexpr (ND == 2) {
+          // (rh wx, rh wy), (rl wx, rl wy) -> [px0, px1, py0, py1] = [rh wx, rl wx, rh wy, rl wy]
+          const u32 p0 = (u32)ea.y, p1 = (u32)ea.z;
+          reinterpret_cast<u32 *>(wp_)[0] = (p0 & 0xffffu) | (p1 << 16);
+          reinterpret_cast<u32 *>(wp_)[1] = (p0 >> 16) | (p1 & 0xffff0000u);
+        } else {
+          const float wx = __int_as_float(ea.y), wy = __int_as_float(ea.z);
+          const float f0l = __int_as_float(ea.w), f0h = __int_as_float(eb.x);
+          const float f1l = __int_as_float(eb.y), f1h = __int_as_float(eb.z);
+          const float fa0 = f0h * f1h, fa1 = f0h * f1l, fa2 = f0l * f1h, fa3 = f0l * f1l;
+          uint2 lo, hi;
+          lo.x = T::pack(fa0 * wx, fa1 * wx); lo.y = T::pack(fa2 * wx, fa3 * wx);
+          hi.x = T::pack(fa0 * wy, fa1 * wy); hi.y = T::pack(fa2 * wy, fa3 * wy);
+          reinterpret_cast<uint2 *>(wp_)[0] = lo;
+          reinterpret_cast<uint2 *>(wp_)[1] = hi;
+        }
+      }
+      // next step's entries: requested before this step's rows (one dependent latency off the loop)
+      const int4 ea_cur = ea, eb_cur = eb;
+      (void)ea_cur; (void)eb_cur;
+      if (e0 + 16 < e_hi) fetch_entry(e0 + 16);
+      // ---- the 16 grad_col rows -> Rt (entries beyond the list: parked out of range, zeros) ----
+      U4 rows[NLD];
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int sr = __shfl(src, i * RPI + r_row, 64);
+        rows[i] = buf_load4u_nt(r_gc, sr >= 0 ? sr * hd.Cp * 2 + c_voff : kHpOob, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        *reinterpret_cast<U4 *>(Rt + (i * RPI + r_row) * PB + r_piece * 8) = rows[i];
+      // ---- 16 entries x 32 NB channels into the window's accumulators ----
+      U4 af;
+      lds_tr2(Wt + fr_row * kWtP + kWtM + fr_col, 4 * kWtP, af);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        U4 bf;
+        lds_tr2(Rt + fr_row * PB + nb * 32 + fr_col, 4 * PB, bf);
+        acc[nb] = T::mfma(af, bf, acc[nb]);
+      }
+      // clear this step's weights (the tile stays zero outside the step's 16 x 2 NS values)
+      if (e_on) {
+        Raw *wp_ = Wt + lane * kWtP + wcol;
+        if constexpr (ND == 2) {
+          reinterpret_cast<u32 *>(wp_)[0] = 0u;
+          reinterpret_cast<u32 *>(wp_)[1] = 0u;
+        } else {
+          reinterpret_cast<uint2 *>(wp_)[0] = make_uint2(0u, 0u);
+          reinterpret_cast<uint2 *>(wp_)[1] = make_uint2(0u, 0u);
+        }
+      }
+    }
+    // ---- flush: rows (anchor - w0) NS + s, contiguous in `sums`; RF rows per pass through the row tile ----
+    Sum *Ft = reinterpret_cast<Sum *>(Rt);   // [RF][CS]
+#pragma unroll
+    for (int ps = 0; ps < 32 / RF; ++ps) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // accumulator r of this lane = row (r & 3) + 8 (r >> 2) + 4 kh, column nb * 32 + pl
+          if ((8 * (r >> 2)) / RF == ps) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh - ps * RF;
+            if constexpr (WIDE) Ft[row * CS + nb * 32 + pl] = acc[nb][r];
+            else T::stf(reinterpret_cast<Raw *>(Ft) + row * CS + nb * 32 + pl, acc[nb][r]);
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int q = lane + 64 * i;                          // 16-byte piece of the pass: 2 CS pieces in all
+        const int row = (q * 16 / (int)sizeof(Sum)) / CS + ps * RF;
+        const U4 v = reinterpret_cast<const U4 *>(Ft)[q];
+        if (w0 + row / NS < S_e)
+          *reinterpret_cast<U4 *>(reinterpret_cast<unsigned char *>(out + (int64_t)w0 * NS * CS) + (size_t)ps * RF * CS * sizeof(Sum) + (size_t)q * 16) = v;
+      }
+    }
+  }
+}
+
 // pass 2: grad_input[b][c][t] (+)= sum_s A[segment(b, c)][anchor row t + s][x][s][c]; workgroup = 64
 // consecutive targets x 64 channels, lanes = (target, channel octet), LDS transpose to [B, C, S_i]
 template <int ND, typename T>
@@ -535,7 +701,19 @@ static int launch_col2im2(const Geom &g, const HpDims &hd, const Tensors &t, con
                        dim3(g.B * g.DG * ((runs_per_seg + runs - 1) / runs)), dim3(256), 0, stream, g, hd, S_e, \
                        (const Raw *)gcol, rowptr, (const int4 *)entries, (typename SumStore<T>::type *)sums); \
   } while (0)
-  if (lanes <= 4) HP_C2S(4);
+  // matrix-core pass 1 where a list's channels are 32 / 64 / 128 / 256 (MDCONV_HP_SUMS=0: the VALU kernel)
+  static const int sums_env = getenv("MDCONV_HP_SUMS") ? atoi(getenv("MDCONV_HP_SUMS")) : 1;
+  const int nb = cseg / 32;
+  if (sums_env && cseg % 32 == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8)) {
+    const int runs = g.B * g.DG * ((S_e + kRunM - 1) / kRunM);
+    const size_t lds = (size_t)4 * (16 * kWtP * 2 + 16 * (cseg + 32) * 2);
+#define HP_C2M(NBV)                                                                              \
+    hipLaunchKernelGGL((hp_col2im_sums_mfma_kernel<ND, T, NBV>), dim3((runs + 3) / 4), dim3(256), lds, stream, g, hd, \
+                       S_e, (const Raw *)gcol, rowptr, (const int4 *)entries, (typename SumStore<T>::type *)sums)
+    if (nb == 1) HP_C2M(1); else if (nb == 2) HP_C2M(2); else if (nb == 4) HP_C2M(4); else HP_C2M(8);
+#undef HP_C2M
+  }
+  else if (lanes <= 4) HP_C2S(4);
   else if (lanes <= 8) HP_C2S(8);
   else if (lanes <= 16) HP_C2S(16);
   else if (lanes <= 32) HP_C2S(32);
