@@ -519,6 +519,8 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_mfma_kernel(Geom g, HpDims
       for (int i = 0; i < NLD; ++i)
         *reinterpret_cast<U4 *>(Rt + (i * RPI + r_row) * PB + r_piece * 8) = rows[i];
       // ---- 16 entries x 32 NB channels into the window's accumulators ----
+      // (compiler fences: the tiles are written and read through differently typed pointers)
+      asm volatile("" ::: "memory");
       U4 af;
       lds_tr2(Wt + fr_row * kWtP + kWtM + fr_col, 4 * kWtP, af);
 #pragma unroll
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_mfma_kernel(Geom g, HpDims
         lds_tr2(Rt + fr_row * PB + nb * 32 + fr_col, 4 * PB, bf);
         acc[nb] = T::mfma(af, bf, acc[nb]);
       }
+      asm volatile("" ::: "memory");
       // clear this step's weights (the tile stays zero outside the step's 16 x 2 NS values)
       if (e_on) {
         Raw *wp_ = Wt + lane * kWtP + wcol;
@@ -554,6 +557,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_mfma_kernel(Geom g, HpDims
             else T::stf(reinterpret_cast<Raw *>(Ft) + row * CS + nb * 32 + pl, acc[nb][r]);
           }
         }
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int q = lane + 64 * i;                          // 16-byte piece of the pass: 2 CS pieces in all
@@ -562,6 +566,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_mfma_kernel(Geom g, HpDims
         if (w0 + row / NS < S_e)
           *reinterpret_cast<U4 *>(reinterpret_cast<unsigned char *>(out + (int64_t)w0 * NS * CS) + (size_t)ps * RF * CS * sizeof(Sum) + (size_t)q * 16) = v;
       }
+      asm volatile("" ::: "memory");
     }
   }
 }
