@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
 // flush (half of that kernel's instructions at cfg3) becomes ONE contiguous 32-row store per window.
 //   * a wave owns a run of kRunM consecutive anchors = kRunM / AW windows; per window it streams the entries of
 //     anchors [w0 - 1, w0 + AW) (the carry-in anchor's entries were read by the previous window a moment ago: an L2 hit);
-//   * per step: lanes 0-15 fetch one entry each (the next step's entries are requested one step ahead), turn it
+//   * per step: lanes 0-15 fetch one entry each (entries run two steps ahead, rows one step ahead), turn it
 //     into 2 NS weights in the tensors' 16-bit type and drop them into a zeroed wave-private LDS tile Wt[16][40] at
 //     column 4 + NS (anchor - w0) (a margin of 4 columns takes the carry-in anchor, the right margin the carry-out);
 //     all lanes fetch the 16 grad_col rows (cseg / 8 lanes per row, 16 bytes each) into the tile R[16][cseg + 32];
@@ -422,7 +422,7 @@ constexpr int kWtP = 40;     // pitch (16-bit elements) of the weight tile: 4 ma
 constexpr int kWtM = 4;      // left margin
 
 template <int ND, typename T, int NB>
-__global__ __launch_bounds__(256) void hp_col2im_sums_mfma_kernel(Geom g, HpDims hd, int S_e,
+__global__ __launch_bounds__(256, NB <= 2 ? 4 : (NB == 4 ? 3 : 1)) void hp_col2im_sums_mfma_kernel(Geom g, HpDims hd, int S_e,
                                                                   const typename T::Raw *__restrict__ gcol,
                                                                   const int *__restrict__ rowptr,
                                                                   const int4 *__restrict__ entries,
@@ -468,34 +468,47 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_mfma_kernel(Geom g, HpDims
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    // entry of this lane for the step that starts at e0 (lanes 0-15)
-    int4 ea = make_int4(0, 0, 0, 0), eb = make_int4(0, 0, 0, 0);
+    // Software pipeline over the steps of the window (16 entries each): the entries run TWO steps ahead of the
+    // matrix work and the grad_col rows ONE step ahead -- a step's rows are requested while the previous step is
+    // multiplied, so the entry -> row dependency costs one exposed round trip per window, not per step
+    struct Ent { int4 a, b; };
     auto fetch_entry = [&](int e0) {
+      Ent en = {make_int4(-1, 0, 0, 0), make_int4(0, 0, 0, 0)};   // beyond the list: row -1 (parked), no weights
       const int e = e0 + lane;
       if (lane < 16 && e < e_hi) {
-        if constexpr (ND == 2) ea = ent[e];
-        else { ea = ent[(int64_t)e * 2]; eb = ent[(int64_t)e * 2 + 1]; }
+        if constexpr (ND == 2) en.a = ent[e];
+        else { en.a = ent[(int64_t)e * 2]; en.b = ent[(int64_t)e * 2 + 1]; }
+      }
+      return en;
+    };
+    U4 rows_cur[NLD], rows_nxt[NLD];
+    auto request_rows = [&](U4 (&rows)[NLD], const Ent &en) {   // entries beyond the list: parked out of range, zeros
+      const int src = lane < 16 ? en.a.x : -1;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int sr = __shfl(src, i * RPI + r_row, 64);
+        rows[i] = buf_load4u_nt(r_gc, sr >= 0 ? sr * hd.Cp * 2 + c_voff : kHpOob, 0);
       }
     };
-    fetch_entry(e_lo);
+    Ent en0 = fetch_entry(e_lo), en1 = fetch_entry(e_lo + 16);
+    if (e_lo < e_hi) request_rows(rows_cur, en0);
     for (int e0 = e_lo; e0 < e_hi; e0 += 16) {
-      // ---- weights of this step's entries -> Wt; row index for the row loads ----
-      const bool e_on = lane < 16 && e0 + lane < e_hi;
-      const int src = e_on ? ea.x : -1;
+      // ---- weights of this step's entries -> Wt ----
+      const bool e_on = lane < 16 && en0.a.x >= 0;
       int wcol = 0;                                    // column of this entry's first weight
       if (e_on) {
-        const int anc = ND == 2 ? ea.w : eb.w;
+        const int anc = ND == 2 ? en0.a.w : en0.b.w;
         wcol = kWtM + NS * (anc - w0);                 // anc in [w0 - 1, w0 + AW): columns [kWtM - NS, kWtM + 32)
         Raw *wp_ = Wt + lane * kWtP + wcol;
         if constexpr (ND == 2) {
           // (rh wx, rh wy), (rl wx, rl wy) -> [px0, px1, py0, py1] = [rh wx, rl wx, rh wy, rl wy]
-          const u32 p0 = (u32)ea.y, p1 = (u32)ea.z;
+          const u32 p0 = (u32)en0.a.y, p1 = (u32)en0.a.z;
           reinterpret_cast<u32 *>(wp_)[0] = (p0 & 0xffffu) | (p1 << 16);
           reinterpret_cast<u32 *>(wp_)[1] = (p0 >> 16) | (p1 & 0xffff0000u);
         } else {
-          const float wx = __int_as_float(ea.y), wy = __int_as_float(ea.z);
-          const float f0l = __int_as_float(ea.w), f0h = __int_as_float(eb.x);
-          const float f1l = __int_as_float(eb.y), f1h = __int_as_float(eb.z);
+          const float wx = __int_as_float(en0.a.y), wy = __int_as_float(en0.a.z);
+          const float f0l = __int_as_float(en0.a.w), f0h = __int_as_float(en0.b.x);
+          const float f1l = __int_as_float(en0.b.y), f1h = __int_as_float(en0.b.z);
           const float fa0 = f0h * f1h, fa1 = f0h * f1l, fa2 = f0l * f1h, fa3 = f0l * f1l;
           uint2 lo, hi;
           lo.x = T::pack(fa0 * wx, fa1 * wx); lo.y = T::pack(fa2 * wx, fa3 * wx);
@@ -504,20 +517,14 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_mfma_kernel(Geom g, HpDims
           reinterpret_cast<uint2 *>(wp_)[1] = hi;
         }
       }
-      // next step's entries: requested before this step's rows (one dependent latency off the loop)
-      const int4 ea_cur = ea, eb_cur = eb;
-      (void)ea_cur; (void)eb_cur;
-      if (e0 + 16 < e_hi) fetch_entry(e0 + 16);
-      // ---- the 16 grad_col rows -> Rt (entries beyond the list: parked out of range, zeros) ----
-      U4 rows[NLD];
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int sr = __shfl(src, i * RPI + r_row, 64);
-        rows[i] = buf_load4u_nt(r_gc, sr >= 0 ? sr * hd.Cp * 2 + c_voff : kHpOob, 0);
-      }
+      // ---- next step's rows and the entries after that: in flight behind this step's rows ----
+      const bool more = e0 + 16 < e_hi;
+      if (more) request_rows(rows_nxt, en1);
+      const Ent en2 = fetch_entry(e0 + 32);
+      // ---- this step's 16 grad_col rows -> Rt ----
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
-        *reinterpret_cast<U4 *>(Rt + (i * RPI + r_row) * PB + r_piece * 8) = rows[i];
+        *reinterpret_cast<U4 *>(Rt + (i * RPI + r_row) * PB + r_piece * 8) = rows_cur[i];
       // ---- 16 entries x 32 NB channels into the window's accumulators ----
       // (compiler fences: the tiles are written and read through differently typed pointers)
       asm volatile("" ::: "memory");
@@ -541,6 +548,10 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_mfma_kernel(Geom g, HpDims
           reinterpret_cast<uint2 *>(wp_)[1] = make_uint2(0u, 0u);
         }
       }
+      en0 = en1;
+      en1 = en2;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) rows_cur[i] = rows_nxt[i];
     }
     // ---- flush: rows (anchor - w0) NS + s, contiguous in `sums`; RF rows per pass through the row tile ----
     Sum *Ft = reinterpret_cast<Sum *>(Rt);   // [RF][CS]
