@@ -717,10 +717,9 @@ static int launch_col2im2(const Geom &g, const HpDims &hd, const Tensors &t, con
                        dim3(g.B * g.DG * ((runs_per_seg + runs - 1) / runs)), dim3(256), 0, stream, g, hd, S_e, \
                        (const Raw *)gcol, rowptr, (const int4 *)entries, (typename SumStore<T>::type *)sums); \
   } while (0)
-  // matrix-core pass 1 where a list's channels are 32 / 64 / 128 / 256 (MDCONV_HP_SUMS=0: the VALU kernel)
-  static const int sums_env = getenv("MDCONV_HP_SUMS") ? atoi(getenv("MDCONV_HP_SUMS")) : 1;
+  // matrix-core pass 1 where a list's channels are 32 / 64 / 128 / 256, the VALU kernel otherwise
   const int nb = cseg / 32;
-  if (sums_env && cseg % 32 == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8)) {
+  if (cseg % 32 == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8)) {
     const int runs = g.B * g.DG * ((S_e + kRunM - 1) / kRunM);
     const size_t lds = (size_t)4 * (16 * kWtP * 2 + 16 * (cseg + 32) * 2);
 #define HP_C2M(NBV)                                                                              \

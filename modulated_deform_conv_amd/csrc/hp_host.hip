@@ -115,8 +115,7 @@ int num_cus();   // mfma_bwd_data.hip
 
 // workgroups per CU the fused backward kernel is sized for when it has 8 + 2 waves (C_in > 128)
 static int hp_wg_per_cu8() {
-  static const int n = getenv("MDCONV_HP_WG8") ? atoi(getenv("MDCONV_HP_WG8")) : 2;
-  return n < 1 ? 1 : n;
+  return 2;
 }
 
 HpDims hp_dims(const Geom &g) {
@@ -177,10 +176,7 @@ HpDims hp_dims(const Geom &g) {
   hd.ranges = (hd.ntiles + hd.tiles_per_range - 1) / hd.tiles_per_range;
   // GEMM-2 (dense, HBM-bound): 4 workgroups per CU in flight, at least 8 tiles per workgroup
   int rw = num_cus() * 4 / g.K;
-  {
-    static const int rw_env = getenv("MDCONV_HP_G2_SLOTS") ? atoi(getenv("MDCONV_HP_G2_SLOTS")) : 0;   // (experiments: workgroups per CU)
-    if (rw_env > 0) rw = num_cus() * rw_env / g.K;
-  }
+  // (one dispatch round -- 3 resident per CU -- or 2 per CU: the cfg5 backward moves by +-0.03 ms, profiles/r05_experiments.md 8)
   if (rw < 1) rw = 1;
   if (rw > hd.max_ranges) hd.max_ranges = rw;
   if (rw > (hd.ntiles + 7) / 8) rw = (hd.ntiles + 7) / 8;

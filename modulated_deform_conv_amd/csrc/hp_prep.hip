@@ -275,11 +275,10 @@ __global__ __launch_bounds__(256) void hp_grad_bias_kernel(Geom g, const typenam
 
 int hp_nchw_to_nhwc(const Geom &g, const HpDims &hd, const void *x, void *xt, hipStream_t stream) {
   const dim3 grid((g.S_i + 63) / 64, (hd.Cp + 63) / 64, g.B);
-  static const bool vec_env = !(getenv("MDCONV_HP_NHWC_VEC") && atoi(getenv("MDCONV_HP_NHWC_VEC")) == 0);
-  if (vec_env && hd.Cp <= 128 && g.S_i % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+  if (hd.Cp <= 128 && g.S_i % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     hipLaunchKernelGGL(hp_nchw_to_nhwc_vec_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
                        (const unsigned short *)x, (unsigned short *)xt);
-  else if (vec_env && g.S_i % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
+  else if (g.S_i % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
     hipLaunchKernelGGL(hp_nchw_to_nhwc_q4_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
                        (const unsigned short *)x, (unsigned short *)xt);
   else

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(Geom g, int ochunks, int 
 // they all hit the same few L2 channels at the same time; 2 / 3 / 6 tiles per workgroup: 1.28 /
 // 1.31 / 1.40 ms vs 1.26 for one; 5 / 3 / 1 taps per workgroup: 1.44 / 1.46 / 2.06 ms.  Round 3, with the
 // tile load no longer exposed: 1 / 2 / 3 / 6 tiles per workgroup of the full rounds = 1.092 / 1.074 / 1.077 /
-// 1.072 ms -- two it is, MDCONV_BD_TPW overrides.)  A tile
+// 1.072 ms -- two it is.)  A tile
 // split between workgroups
 // needs no atomics: grad_col, grad_offset and grad_mask are all per-tap outputs.
 //
@@ -1371,7 +1371,6 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
     }                                                                                           \
     /* complete dispatch rounds of one-tile workgroups (2 per CU by registers, fewer by LDS),  */ \
     /* then the units of the leftover tiles spread over one more, shorter, round              */ \
-    static const int percu_env = getenv("MDCONV_BD_PERCU") ? atoi(getenv("MDCONV_BD_PERCU")) : 0; \
     /* resident workgroups per CU of this instance at THIS dynamic LDS size (it varies with C_out and K for  */ \
     /* one instance: re-queried when the size changes -- advisor, round 4)                                      */ \
     static int occ_q = 0;                                                                       \
@@ -1384,10 +1383,8 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
       occ_q = nq > 0 ? nq : (lds * 2 <= 160 * 1024 ? 2 : 1);                                    \
       occ_lds = lds;                                                                            \
     }                                                                                           \
-    const int per_cu = percu_env > 0 ? percu_env : occ_q;                                       \
-    const int slots = num_cus() * per_cu;                                                       \
-    static const int tpw_env = getenv("MDCONV_BD_TPW") ? atoi(getenv("MDCONV_BD_TPW")) : 2;     \
-    const int tpw = tpw_env > 0 ? tpw_env : 1;   /* whole tiles per workgroup of the full rounds */ \
+    const int slots = num_cus() * occ_q;                                                        \
+    const int tpw = 2;   /* whole tiles per workgroup of the full rounds */                     \
     const int n_full = ntiles / (slots * tpw) * slots;                                          \
     static const bool debug_plan = getenv("MDCONV_DEBUG_PLAN") != nullptr;                      \
     if (debug_plan)                                                                             \

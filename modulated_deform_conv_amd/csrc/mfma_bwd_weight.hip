@@ -39,8 +39,8 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // Wave arrangement: WR x WC waves, MB 32-row tiles per wave -> workgroup tile
 // (WR * MB * 32 output channels) x (WC * 32 input channels):
-//   <4, 1, 2>  256 x 32   the default;
-//   <2, 2, 1>   64 x 64   C_out <= 64 (with the default, three of four waves would be padding).
+//   <4, 1, 2>  256 x 32   (a 64 x 64 arrangement for C_out <= 64 measured slower with NCHW gathers -- GEMM-2 5.4 -> 8 ms at
+//                          cfg4, round 1 -- and is not instantiated any more; narrow shapes run the channels-last kernels).
 template <int ND, bool PADN, int WR, int WC, int MB>
 __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd,
                                                               const float *__restrict__ input,
@@ -298,10 +298,7 @@ int mfma_bwd_weight_occupancy(int nd, bool padn, int wtile) {
 #define OCC_BW(ND, PADN, WR, WC, MB)                                                                           \
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                                          \
       &n, reinterpret_cast<const void *>(&mfma_bwd_weight_kernel<ND, PADN, WR, WC, MB>), 256, 0)
-#define OCC_BW2(ND, PADN)                                                                                      \
-  do {                                                                                                          \
-    if (wtile == 1) OCC_BW(ND, PADN, 2, 2, 1); else OCC_BW(ND, PADN, 4, 1, 2);                                 \
-  } while (0)
+#define OCC_BW2(ND, PADN) OCC_BW(ND, PADN, 4, 1, 2)
   if (nd == 2) { if (padn) OCC_BW2(2, true); else OCC_BW2(2, false); }
   else { if (padn) OCC_BW2(3, true); else OCC_BW2(3, false); }
 #undef OCC_BW2
@@ -325,10 +322,7 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
 #define LAUNCH_BW(ND, PADN, WR, WC, MB)                                                         \
   hipLaunchKernelGGL((mfma_bwd_weight_kernel<ND, PADN, WR, WC, MB>), grid, dim3(256), 0, stream, \
                      g, bd, (const float *)t.input, ga, table, part)
-#define LAUNCH_BW2(ND, PADN)                                                                    \
-  do {                                                                                          \
-    if (bd.wtile == 1) LAUNCH_BW(ND, PADN, 2, 2, 1); else LAUNCH_BW(ND, PADN, 4, 1, 2);         \
-  } while (0)
+#define LAUNCH_BW2(ND, PADN) LAUNCH_BW(ND, PADN, 4, 1, 2)
   if (g.nd == 2) { if (padn) LAUNCH_BW2(2, true); else LAUNCH_BW2(2, false); }
   else { if (padn) LAUNCH_BW2(3, true); else LAUNCH_BW2(3, false); }
 #undef LAUNCH_BW2

@@ -30,9 +30,8 @@ __device__ unsigned long long g_b2_timing[8];
 #endif
 
 // <WR, WC, MB, NBW>: WR x WC waves, each MB x NBW blocks of 32 x 32; WC * NBW * 32 == 64
-//   <2, 2, 1, 1>   64 x 64    C_out <= 64
-//   <2, 2, 2, 1>  128 x 64    C_out <= 128
-//   <4, 1, 2, 2>  256 x 64
+//   <4, 1, 2, 2>  256 x 64   (the narrow tiles -- 64 x 64, 128 x 64 for C_out <= 64 / 128 -- run the 64-pixel-slab
+//                             kernel further down, mfma_bwd_weight_cl64_kernel)
 template <int ND, bool PADN, int WR, int WC, int MB, int NBW>
 __global__ __launch_bounds__(256, 1) void mfma_bwd_weight_cl_kernel(Geom g, BwdDims bd,
                                                                  const float *__restrict__ xt,
@@ -447,17 +446,10 @@ namespace mdconv {
 
 // Resident workgroups per CU of the variant that (nd, padn, wtile, coord) selects: hipOccupancy on the very
 // instance, so the split-K count of bwd_dims() follows the register allocation instead of a constant that rots.
-// MDCONV_BW_SLAB = 0 keeps the 16-pixel-chunk kernel for the narrow tiles too (A/B switch, read once)
-bool bwd_weight_slab_enabled();
-static bool bw_slab_enabled() { return bwd_weight_slab_enabled(); }
-bool bwd_weight_slab_enabled() {
-  static const int v = getenv("MDCONV_BW_SLAB") ? atoi(getenv("MDCONV_BW_SLAB")) : 1;
-  return v != 0;
-}
 #define MDCONV_CL_INSTANCE(ND, PADN, CALL)                                                                     \
   do {                                                                                                          \
-    if (wtile == 1) { if (bw_slab_enabled()) CALL##64(ND, PADN, 1); else CALL(ND, PADN, 2, 2, 1, 1); }          \
-    else if (wtile == 2) { if (bw_slab_enabled()) CALL##64(ND, PADN, 2); else CALL(ND, PADN, 2, 2, 2, 1); }     \
+    if (wtile == 1) { CALL##64(ND, PADN, 1); }                                                                  \
+    else if (wtile == 2) { CALL##64(ND, PADN, 2); }                                                             \
     else { CALL(ND, PADN, 4, 1, 2, 2); }                                                                        \
   } while (0)
 #define MDCONV_CL_DISPATCH(CALL)                                                                               \

@@ -454,11 +454,7 @@ int launch_fwd_tile(const Geom &g, const PackDims &pd, const Tensors &t, const f
 template <int ND, bool MOD>
 int launch_fwd(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,
                hipStream_t stream) {
-  static const char *const v = getenv("MDCONV_FWD_TILE");   // tuning knob: "256x32" | "256x64" (read once)
-  if (pd.BM == 256) {
-    if (v && !strcmp(v, "256x64")) return launch_fwd_tile<ND, MOD, 256, 64, 64, 64>(g, pd, t, wp, part, stream);
-    return launch_fwd_tile<ND, MOD, 256, 32, 64, 32>(g, pd, t, wp, part, stream);
-  }
+  if (pd.BM == 256) return launch_fwd_tile<ND, MOD, 256, 32, 64, 32>(g, pd, t, wp, part, stream);
   if (pd.BM == 128) return launch_fwd_tile<ND, MOD, 128, 64, 64, 32>(g, pd, t, wp, part, stream);
   return launch_fwd_tile<ND, MOD, 64, 128, 64, 32>(g, pd, t, wp, part, stream);
 }

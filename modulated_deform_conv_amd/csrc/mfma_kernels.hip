@@ -124,8 +124,6 @@ BwdDims bwd_dims(const Geom &g) {
   // With channels-last gathers the tile is always 64 input channels wide.
   bd.cl = bwd_channels_last(g) ? 1 : 0;
   bd.wtile = 0;
-  static const int bw_tile_env = getenv("MDCONV_BW_TILE") ? atoi(getenv("MDCONV_BW_TILE")) : 0;
-  if (bw_tile_env == 1 && g.O <= 64) bd.wtile = 1;
   if (bd.cl) bd.wtile = g.O <= 64 ? 1 : (g.O <= 128 ? 2 : 3);
   const int rm = bd.cl ? (bd.wtile == 1 ? 64 : (bd.wtile == 2 ? 128 : 256)) : (bd.wtile ? 64 : 256);
   const int cn = bd.cl ? 64 : (bd.wtile ? 64 : 32);
@@ -140,7 +138,6 @@ BwdDims bwd_dims(const Geom &g) {
   // 1.36 x the resident slots (cfg2 in round 3: 36 column tiles x 29 splits = 1044 workgroups on 256 CUs x 3)
   // runs its last 276 workgroups one per CU at half the matrix rate -- 0.68 of peak where the steady state
   // reaches 0.8+.  slots = CUs x resident workgroups of the instance that will run (hipOccupancy).
-  // MDCONV_BW_SPLITS overrides (experiments).
   const bool padn = bd.Np != g.N;
   const int occ = bd.cl ? mfma_bwd_weight_cl_occupancy(g.nd, padn, bd.wtile)
                         : mfma_bwd_weight_occupancy(g.nd, padn, bd.wtile);
@@ -151,8 +148,6 @@ BwdDims bwd_dims(const Geom &g) {
   const int occ_run = bwd_fork_enabled() && occ > 1 ? occ - 1 : occ;
   const int slots = device_cus() * occ_run;
   int splits = slots / col_tiles;
-  static const int splits_env = getenv("MDCONV_BW_SPLITS") ? atoi(getenv("MDCONV_BW_SPLITS")) : 0;
-  if (splits_env > 0) splits = splits_env;
   if (splits > pairs) splits = pairs;
   if (splits < 1) splits = 1;
   bd.pairs_per_split = (pairs + splits - 1) / splits;
@@ -371,12 +366,10 @@ bool get_fork(hipStream_t stream, Fork *out) {
   // A stream of ANOTHER priority class: HIP multiplexes the streams of one class over a few hardware queues,
   // and once a process holds more streams (RCCL's, after init_process_group) the side stream can land on the
   // caller's queue -- the two tails then run one after the other again (measured: 3.44 -> 3.65 ms per cfg2
-  // step under torchrun).  Priority classes have their own queues.  MDCONV_FORK_PRIO = -1 | 0 | 1 overrides.
+  // step under torchrun).  Priority classes have their own queues.
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  static const int prio_env = getenv("MDCONV_FORK_PRIO") ? atoi(getenv("MDCONV_FORK_PRIO")) : -1;
-  const int prio = prio_env < 0 ? greatest : (prio_env > 0 ? least : 0);
-  if (hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, prio) != hipSuccess) return false;
+  if (hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, greatest) != hipSuccess) return false;
   if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&f.bias, hipEventDisableTiming) != hipSuccess)
@@ -420,15 +413,8 @@ int backward_chunk_f32(const Geom &g, const Tensors &t, char *base, hipStream_t 
   float *bstage = g.with_bias ? (float *)(base + bd.off_bstage) : nullptr;
   // channels-last copy of the input for the 3-D gathers of GEMM-1's drain and of GEMM-2
   float *xt = bd.cl ? (float *)(base + bd.off_xt) : nullptr;
-  // pack_wq, counter clearing and the layout pass: one launch (MDCONV_BWD_PREP=0: three, the round-4 sequence)
-  static const int prep_env = getenv("MDCONV_BWD_PREP") ? atoi(getenv("MDCONV_BWD_PREP")) : 1;
-  if (prep_env) {
-    if ((rc = bwd_prep_f32(g, bd, (const float *)t.weight, wq, cnt, (const float *)t.input, xt, stream))) return rc;
-  } else {
-    if ((rc = pack_wq_f32(g, bd, (const float *)t.weight, wq, stream))) return rc;
-    if ((rc = csr_zero_f32(g, bd, cnt, stream))) return rc;
-    if (bd.cl && (rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream))) return rc;
-  }
+  // pack_wq, counter clearing and the layout pass: one launch
+  if ((rc = bwd_prep_f32(g, bd, (const float *)t.weight, wq, cnt, (const float *)t.input, xt, stream))) return rc;
   profile_mark(1, true, stream, "mfma_bwd_data_kernel");
   rc = mfma_bwd_data_f32(g, bd, t, wq, gcol, ga, bias_part, cnt, table, xt, stream);
   profile_mark(1, false, stream);

@@ -132,7 +132,6 @@ int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, cons
                         hipStream_t stream);
 int mfma_bwd_weight_cl_launch(const Geom &g, const BwdDims &bd, const float *xt, const float *ga,
                               const int *table, float *part, hipStream_t stream);
-bool bwd_weight_slab_enabled();   // the 64-pixel-slab GEMM-2 of the narrow tiles is on (MDCONV_BW_SLAB)
 // resident workgroups per CU of the GEMM-2 instance a shape selects (hipOccupancy, cached); device_cus() = CUs of
 // the current device (256 on MI355X; the same figure without a device, for host-only callers)
 int mfma_bwd_weight_cl_occupancy(int nd, bool padn, int wtile);
