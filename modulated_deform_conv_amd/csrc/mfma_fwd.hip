@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
                                                        const float *__restrict__ offset,
                                                        const float *__restrict__ mask,
                                                        float *__restrict__ output, int ntm, int ntn,
-                                                       int full_tiles, int tail_ways, float *__restrict__ part) {
+                                                       int full_tiles, int tail_ways, int tail_hi,
+                                                       float *__restrict__ part) {
   constexpr int BK = kBK;
   constexpr int NC = 1 << ND;
   constexpr int NP = NC / 2;                  // corner pairs along the contiguous axis
@@ -80,11 +81,23 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   if ((int)blockIdx.x < full_tiles) {
     tile = xcd_remap(blockIdx.x, full_tiles);
   } else {
+    // the first tail_hi tail tiles are cut into tail_ways + 1 ranges, the others into tail_ways (fwd_tail_plan)
     tail_slot = blockIdx.x - full_tiles;
-    const int ti = tail_slot / tail_ways, way = tail_slot - ti * tail_ways;
+    const int hi_slots = tail_hi * (tail_ways + 1);
+    int ti, way, wt;
+    if (tail_slot < hi_slots) {
+      wt = tail_ways + 1;
+      ti = tail_slot / wt;
+      way = tail_slot - ti * wt;
+    } else {
+      wt = tail_ways;
+      const int r = tail_slot - hi_slots;
+      ti = tail_hi + r / wt;
+      way = r - (r / wt) * wt;
+    }
     tile = full_tiles + ti;
-    tap_lo = way * g.K / tail_ways;
-    tap_hi = (way + 1) * g.K / tail_ways;
+    tap_lo = way * g.K / wt;
+    tap_hi = (way + 1) * g.K / wt;
   }
   const int tn = tile / ntm, tm = tile - tn * ntm;
   const int o0 = tm * BM;
@@ -364,18 +377,21 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void fwd_tail_reduce_kernel(Geom g, const float *__restrict__ part,
                                                               const float *__restrict__ bias,
                                                               float *__restrict__ output, int ntm,
-                                                              int full_tiles, int tail_ways) {
+                                                              int full_tiles, int tail_ways, int tail_hi) {
   // grid = (tail tiles, kSlices): a slice of 512 elements per workgroup (one workgroup per tile walked its 8192
   // elements in 32 dependent rounds: 29 us for 64 tiles at cfg2)
   const int tile = full_tiles + blockIdx.x;
   const int tn = tile / ntm, tm = tile - tn * ntm;
-  const float *src = part + (size_t)blockIdx.x * tail_ways * (BM * BN);
+  const int ti = blockIdx.x;
+  const int slot0 = ti < tail_hi ? ti * (tail_ways + 1) : tail_hi * (tail_ways + 1) + (ti - tail_hi) * tail_ways;
+  const int nways = ti < tail_hi ? tail_ways + 1 : tail_ways;
+  const float *src = part + (size_t)slot0 * (BM * BN);
   const int e_lo = blockIdx.y * (BM * BN / kTailSlices);
   for (int e = e_lo + threadIdx.x; e < e_lo + BM * BN / kTailSlices; e += 256) {
     const int ol = tm * BM + e / BN, n = tn * BN + e % BN;
     if (ol >= g.Og || n >= g.N) continue;
     float sacc = src[e];
-    for (int w = 1; w < tail_ways; ++w) sacc += src[(size_t)w * (BM * BN) + e];
+    for (int w = 1; w < nways; ++w) sacc += src[(size_t)w * (BM * BN) + e];
     const int b = n / g.S_o, pix = n - b * g.S_o;
     output[(int64_t)(b * g.O + ol) * g.S_o + pix] = sacc + (g.with_bias ? bias[ol] : 0.f);
   }
@@ -383,26 +399,48 @@ __global__ __launch_bounds__(256) void fwd_tail_reduce_kernel(Geom g, const floa
 
 constexpr int kTailMaxPerCu = 5;   // resident workgroups per CU the tail plan and its scratch are sized for
 
-// Tail plan of a tile grid (see the kernel): tiles that fill whole dispatch rounds, and the number of tap ranges
-// the leftover tiles are cut into so that their workgroups still fit one round.  MDCONV_FWD_TAIL=0 disables.
-void fwd_tail_plan(const Geom &g, int tiles, int slots, int *full_tiles, int *ways) {
-  static const int tail_env = getenv("MDCONV_FWD_TAIL") ? atoi(getenv("MDCONV_FWD_TAIL")) : 1;
+// Tail plan of a tile grid (see the kernel): `full` tiles run whole, the others -- the leftover of the last dispatch
+// round, or every tile of a grid smaller than one round -- are cut into tap ranges so that the round is FULL: with
+// `rem` tiles on `slots` slots, n_hi = slots - rem * w tiles get w + 1 ranges and the rest w = slots / rem (w = 1:
+// those stay whole).  Round 4 only split behind a full round and uniformly (cfg2: 64 leftover tiles x 4 ranges); cutting
+// EVERY tile of the B = 4 shard in two (784 workgroups on 1024 slots: again a ragged round) had measured slower
+// (0.189 -> 0.211 ms).  At most 4 ranges (each pays a prologue, a 32 KB partial tile and its share of the reduction:
+// cfg2 1.005 ms unsplit, 0.979 / 0.984 / 0.981 with 2 / 3 / 4 ranges, 1.027 with 9).  MDCONV_FWD_TAIL=0 disables, =1
+// restores the round-4 plan (uniform, only behind a full round).
+void fwd_tail_plan(const Geom &g, int tiles, int slots, int *full_tiles, int *ways, int *n_hi) {
+  static const int tail_env = getenv("MDCONV_FWD_TAIL") ? atoi(getenv("MDCONV_FWD_TAIL")) : 2;
   *full_tiles = tiles;
   *ways = 1;
+  *n_hi = 0;
   if (!tail_env || g.G != 1 || g.K < 2 || slots <= 0) return;
   const int rem = tiles % slots;
-  // only behind at least one full round: a grid that does not fill the chip once gains nothing from more, shorter
-  // workgroups (cfg2 at B = 4, 392 tiles on 1024 slots, every tile cut in two: 0.189 -> 0.211 ms)
-  if (rem == 0 || tiles < slots) return;
+  if (rem == 0) return;
   int w = slots / rem;
-  if (w > g.K) w = g.K;
-  // at most 4 ranges: every range pays a prologue, a partial-tile store and its share of the reduction pass
-  // (cfg2, 64 leftover tiles: 1.005 ms unsplit, 0.979 / 0.984 / 0.981 with 2 / 3 / 4 ranges, 1.027 with 9)
-  const int cap = tail_env > 1 ? tail_env : 4;
-  if (w > cap) w = cap;
-  if (w < 2) return;
+  const int cap = g.K < 4 ? g.K : 4;
+  if (tail_env == 1) {
+    if (tiles < slots) return;
+    if (w > cap) w = cap;
+    if (w < 2) return;
+    *full_tiles = tiles - rem;
+    *ways = w;
+    return;
+  }
+  if (w >= cap) {            // few leftover tiles: the cap, uniformly (the round stays partly empty)
+    *full_tiles = tiles - rem;
+    *ways = cap;
+    return;
+  }
+  const int hi = slots - rem * w;          // tiles that take one range more: rem * w + hi = slots
+  if (w == 1) {                            // the tiles with one range are whole tiles
+    if (hi == 0) return;
+    *full_tiles = tiles - hi;
+    *ways = 1;
+    *n_hi = hi;
+    return;
+  }
   *full_tiles = tiles - rem;
   *ways = w;
+  *n_hi = hi;
 }
 
 template <int ND, bool MOD, int BM, int BN, int WM, int WN, bool PADK>
@@ -425,22 +463,22 @@ int launch_fwd_tile_k(const Geom &g, const PackDims &pd, const Tensors &t, const
                       hipStream_t stream) {
   const int ntm = (g.Og + BM - 1) / BM;
   const int ntn = (g.N + BN - 1) / BN;
-  int full_tiles, ways;
-  fwd_tail_plan(g, ntm * ntn, part ? fwd_tile_slots<ND, MOD, BM, BN, WM, WN, PADK>() : 0, &full_tiles, &ways);
+  int full_tiles, ways, n_hi;
+  fwd_tail_plan(g, ntm * ntn, part ? fwd_tile_slots<ND, MOD, BM, BN, WM, WN, PADK>() : 0, &full_tiles, &ways, &n_hi);
   const int tail_tiles = ntm * ntn - full_tiles;
   static const bool debug_plan = getenv("MDCONV_DEBUG_PLAN") != nullptr;
   if (debug_plan)
-    fprintf(stderr, "[mdconv] forward plan: %d x %d tile, %d tiles, slots %d, full %d, tail %d x %d tap ranges\n", BM, BN,
-            ntm * ntn, part ? fwd_tile_slots<ND, MOD, BM, BN, WM, WN, PADK>() : 0, full_tiles, tail_tiles, ways);
-  dim3 grid(full_tiles + tail_tiles * ways, g.G);
+    fprintf(stderr, "[mdconv] forward plan: %d x %d tile, %d tiles, slots %d, full %d, tail %d x %d tap ranges (%d of them x %d)\n", BM, BN,
+            ntm * ntn, part ? fwd_tile_slots<ND, MOD, BM, BN, WM, WN, PADK>() : 0, full_tiles, tail_tiles, ways, n_hi, ways + 1);
+  dim3 grid(full_tiles + tail_tiles * ways + n_hi, g.G);
   hipLaunchKernelGGL((mfma_fwd_kernel<ND, MOD, BM, BN, WM, WN, PADK>), grid, dim3(256), 0, stream,
                      g, pd, (const float *)t.input, wp, (const float *)t.bias,
                      (const float *)t.offset, (const float *)t.mask, (float *)t.output, ntm, ntn,
-                     full_tiles, ways, part);
+                     full_tiles, ways, n_hi, part);
   int rc = check_launch("mfma_fwd");
   if (rc || tail_tiles == 0) return rc;
   hipLaunchKernelGGL((fwd_tail_reduce_kernel<BM, BN>), dim3(tail_tiles, kTailSlices), dim3(256), 0, stream, g, part,
-                     (const float *)t.bias, (float *)t.output, ntm, full_tiles, ways);
+                     (const float *)t.bias, (float *)t.output, ntm, full_tiles, ways, n_hi);
   return check_launch("fwd_tail_reduce");
 }
 
