@@ -71,11 +71,15 @@ __global__ __launch_bounds__(256) void hp_csr_scan_kernel(int S, const int *__re
   if (hi == S && threadIdx.x == 0) rp[S] = carry;
 }
 
-// 3-D entry = 2 x int4: (src, wx, wy, rl0), (rh0, rl1, rh1, anchor).
-// 2-D entry = 1 x int4 (round 4: half the list bytes; cfg3 writes 3.6 M of them): (src, (rh0 wx, rh0 wy), (rl0 wx,
-// rl0 wy), anchor) -- the four weight products the gathers use (mask folded in), as two packed pairs in the TENSORS'
-// 16-bit type: as many significant bits as the grad_col rows they multiply carry, and the range of the mask tensor
-// itself (a bf16 mask above 65504 or a product below 6e-8 would be lost in fp16 pairs -- advisor, round 4).
+// Long entry = 2 x int4, fp32 fields: (src, wx, wy, rl0), (rh0, rl1, rh1, anchor)  [2-D: rl1 = rl0, rh1 = rh0].
+// Short entry = 1 x int4 (round 4: half the list bytes; cfg3 writes 3.6 M of them), 2-D fp16 tensors only:
+// (src, (rh0 wx, rh0 wy), (rl0 wx, rl0 wy), anchor) -- the four weight x mask products as two packed fp16 pairs: 11
+// significant bits, what the fp16 grad_col rows they multiply carry, and the mask of an fp16 call cannot leave the fp16
+// range.  bf16 tensors keep LONG entries in 2-D too (round 5): fp16 pairs would lose a bf16 mask above 65504 or a
+// product below 6e-8 (advisor, round 4), bf16 pairs would round every weight to 8 bits -- a second rounding per term
+// that `test_bf16_two_pass_gather_rounds_once_like_the_one_pass_gather` (and its 2-D sibling) forbid.
+template <int ND, typename T> struct ShortEntry { static constexpr bool value = false; };
+template <> struct ShortEntry<2, F16> { static constexpr bool value = true; };
 template <int ND, bool MOD, typename T>
 __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
                                                           const typename T::Raw *__restrict__ offset,
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void hp_csr_fill_kernel(Geom g, int S_e,
     if (sa.on) {
       // the counters double as cursors, counted down: no clearing pass between scan and fill
       const int pos = rowptr[(int64_t)seg * (S_e + 1) + sa.qa] + atomicSub(cursor + (int64_t)seg * S_e + sa.qa, 1) - 1;
-      if constexpr (ND == 2) {
+      if constexpr (ShortEntry<ND, T>::value) {
         entries[(int64_t)seg * ((int64_t)g.K * g.S_o) + pos] =
             make_int4(tap * g.S_o + pix, (int)T::pack(sa.rh[0] * sa.wx, sa.rh[0] * sa.wy),
                       (int)T::pack(sa.rl[0] * sa.wx, sa.rl[0] * sa.wy), sa.qa);
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
     const bool chan_on = c8 < c_end;
     const int seg = b * g.DG + dg;
     const int *rp = rowptr + (int64_t)seg * (S_e + 1);
-    const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * (ND == 2 ? 1 : 2);
+    const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * (ShortEntry<ND, T>::value ? 1 : 2);
     const int c_voff = chan_on ? c8 * 2 : kHpOob;
     // coordinates of the target of the current step (first step: qs - 1, the carry-in column)
     int tc[ND];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
           float fx_m = 0.f, fy_m = 0.f;   // weights 0, row 0 beyond the list
           if (r < cnt) {
             // target = low + 1 - s_a on axis a: s_a = 1 -> the low side (rl), 0 -> the high side (rh)
-            if constexpr (ND == 2) {
+            if constexpr (ShortEntry<ND, T>::value) {
               const int4 e4 = ent[base + r];
               const u32 pr = (u32)(s ? e4.z : e4.y);
               src_m = e4.x;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
             } else {
               const int4 ea4 = ent[(int64_t)(base + r) * 2], eb4 = ent[(int64_t)(base + r) * 2 + 1];
               float rw = ((s >> (L - 1)) & 1) ? __int_as_float(ea4.w) : __int_as_float(eb4.x);
-              rw *= (s & 1) ? __int_as_float(eb4.y) : __int_as_float(eb4.z);
+              if (ND == 3) rw *= (s & 1) ? __int_as_float(eb4.y) : __int_as_float(eb4.z);
               src_m = ea4.x;
               fx_m = rw * __int_as_float(ea4.y);
               fy_m = rw * __int_as_float(ea4.z);
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   const int a_last = run_on ? min(a_lo + kRunA, S_e) - 1 : -1;  // last one
   const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * hd.Cp, (size_t)g.K * g.S_o * hd.Cp * 2);
   const int *rp = rowptr + (int64_t)seg * (S_e + 1);
-  const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * (ND == 2 ? 1 : 2);
+  const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * (ShortEntry<ND, T>::value ? 1 : 2);
   const bool chan_on = r * 8 < cseg;
   const int c_voff = chan_on ? (dg * cseg + r * 8) * 2 : kHpOob;
   Sum *out = sums + ((int64_t)seg * S_e * NS) * cseg + r * 8;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
 #pragma unroll
     for (int s = 0; s < NS; ++s) px_m[s] = py_m[s] = 0.f;
     if (e_pos + r < e_end) {
-      if constexpr (ND == 2) {
+      if constexpr (ShortEntry<ND, T>::value) {
         const int4 e4 = ent[e_pos + r];
         src_m = e4.x;
         px_m[0] = T::lo((u32)e4.y); py_m[0] = T::hi((u32)e4.y);
@@ -351,7 +355,8 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
         const float wx = __int_as_float(ea4.y), wy = __int_as_float(ea4.z);
         const float f0l = __int_as_float(ea4.w), f0h = __int_as_float(eb4.x);
         const float f1l = __int_as_float(eb4.y), f1h = __int_as_float(eb4.z);
-        const float fa[4] = {f0h * f1h, f0h * f1l, f0l * f1h, f0l * f1l};
+        // s: bit a set = the target one lower on outer axis a (weight rl_a), clear = rh_a; 2-D has one outer axis
+        const float fa[4] = {ND == 3 ? f0h * f1h : f0h, ND == 3 ? f0h * f1l : f0l, f0l * f1h, f0l * f1l};
 #pragma unroll
         for (int s = 0; s < NS; ++s) { px_m[s] = fa[s] * wx; py_m[s] = fa[s] * wy; }
         anc_m = eb4.w;
@@ -430,6 +435,9 @@ __global__ __launch_bounds__(256, NB <= 2 ? 4 : (NB == 4 ? 3 : 1)) void hp_col2i
   using Raw = typename T::Raw;
   using Sum = typename SumStore<T>::type;
   constexpr bool WIDE = sizeof(Sum) == 4;
+  // fp16 tensors only: the weights enter the matrix core in the tensors' type, and 8-bit bf16 weights would be a second
+  // rounding per term (bf16 tensors keep the fp32-weight VALU kernel above)
+  static_assert(ShortEntry<2, T>::value, "fp16 tensors only");
   constexpr int L = ND - 1, NS = 1 << L, AW = 32 / NS;
   constexpr int CS = NB * 32;              // channels that share one list
   constexpr int PB = CS + 32;              // pitch of the row tile
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256, NB <= 2 ? 4 : (NB == 4 ? 3 : 1)) void hp_col2i
   const int b = seg / g.DG, dg = seg - b * g.DG;
   const rsrc_t r_gc = make_rsrc(gcol + (size_t)b * g.K * g.S_o * hd.Cp, (size_t)g.K * g.S_o * hd.Cp * 2);
   const int *rp = rowptr + (int64_t)seg * (S_e + 1);
-  const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * (ND == 2 ? 1 : 2);
+  const int4 *ent = entries + (int64_t)seg * ((int64_t)g.K * g.S_o) * (ShortEntry<ND, T>::value ? 1 : 2);
   Sum *out = sums + ((int64_t)seg * S_e * NS) * CS;
   // this lane's piece of a grad_col row in the row role: row (lane / LPR) of a wave-load, 16 bytes at channel 8 (lane % LPR)
   const int r_row = lane / LPR, r_piece = lane % LPR;
@@ -717,17 +725,22 @@ static int launch_col2im2(const Geom &g, const HpDims &hd, const Tensors &t, con
                        dim3(g.B * g.DG * ((runs_per_seg + runs - 1) / runs)), dim3(256), 0, stream, g, hd, S_e, \
                        (const Raw *)gcol, rowptr, (const int4 *)entries, (typename SumStore<T>::type *)sums); \
   } while (0)
-  // matrix-core pass 1 where a list's channels are 32 / 64 / 128 / 256, the VALU kernel otherwise
+  // matrix-core pass 1 for fp16 tensors where a list's channels are 32 / 64 / 128 / 256, the VALU kernel otherwise
   const int nb = cseg / 32;
-  if (cseg % 32 == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8)) {
-    const int runs = g.B * g.DG * ((S_e + kRunM - 1) / kRunM);
-    const size_t lds = (size_t)4 * (16 * kWtP * 2 + 16 * (cseg + 32) * 2);
+  bool on_mfma = false;
+  if constexpr (ShortEntry<2, T>::value) {   // (F16: the trait names the tensor type)
+    if (cseg % 32 == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8)) {
+      const int runs = g.B * g.DG * ((S_e + kRunM - 1) / kRunM);
+      const size_t lds = (size_t)4 * (16 * kWtP * 2 + 16 * (cseg + 32) * 2);
 #define HP_C2M(NBV)                                                                              \
-    hipLaunchKernelGGL((hp_col2im_sums_mfma_kernel<ND, T, NBV>), dim3((runs + 3) / 4), dim3(256), lds, stream, g, hd, \
-                       S_e, (const Raw *)gcol, rowptr, (const int4 *)entries, (typename SumStore<T>::type *)sums)
-    if (nb == 1) HP_C2M(1); else if (nb == 2) HP_C2M(2); else if (nb == 4) HP_C2M(4); else HP_C2M(8);
+      hipLaunchKernelGGL((hp_col2im_sums_mfma_kernel<ND, T, NBV>), dim3((runs + 3) / 4), dim3(256), lds, stream, g, hd, \
+                         S_e, (const Raw *)gcol, rowptr, (const int4 *)entries, (typename SumStore<T>::type *)sums)
+      if (nb == 1) HP_C2M(1); else if (nb == 2) HP_C2M(2); else if (nb == 4) HP_C2M(4); else HP_C2M(8);
 #undef HP_C2M
+      on_mfma = true;
+    }
   }
+  if (on_mfma) {}
   else if (lanes <= 4) HP_C2S(4);
   else if (lanes <= 8) HP_C2S(8);
   else if (lanes <= 16) HP_C2S(16);

@@ -103,6 +103,21 @@ def test_cfg2_linearity_shards_instep_determinism(cfg2):
     assert_close("grad_bias", parts[0][1][4] + parts[1][1][4], g[4], 1e-4)
 
 
+@pytest.mark.parametrize("nb", [4, 8])
+def test_cfg2_small_shards_match_the_full_batch(cfg2, nb):
+    """The strong-scaling shards (4 / 8 images of cfg2's 32): their forward runs ONE dispatch round made of tap-range
+    workgroups of mixed length (mfma_fwd.hip, fwd_tail_plan: 392 tiles -> 240 x 3 + 152 x 2 ranges; 784 tiles -> 544 whole +
+    240 x 2), a plan no other test shape reaches.  Per-image results equal the full-batch run's to fp32 re-association."""
+    x, off, m, w, b, go = cfg2
+    out, g, _ = _mdcn2d(x, off, m, w, b, go, "auto")
+    s = slice(8, 8 + nb)
+    o2, g2, _ = _mdcn2d(x[s].contiguous(), off[s].contiguous(), m[s].contiguous(), w, b, go[s].contiguous(), "auto")
+    assert_close("output", o2, out[s], 1e-5)
+    assert_close("grad_input", g2[0], g[0][s], 1e-5)
+    assert_close("grad_offset", g2[1], g[1][s], 1e-5)
+    assert_close("grad_mask", g2[2], g[2][s], 1e-5)
+
+
 BITSTABLE_CODE = r"""
 import sys
 sys.path.insert(0, %r)
