@@ -783,6 +783,38 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     const float4 b0 = *reinterpret_cast<const float4 *>(bp);
     const float4 b1 = *reinterpret_cast<const float4 *>(bp + 8);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef ABL_B1_BF16X3
+    // Developer ablation (TIMING ONLY, results are wrong): the instruction mix of a three-term bf16 split of this chunk's
+    // K = 16 product -- the 8 grad_out values of the lane split into hi / mid / lo bf16 planes on the fly (real code), six
+    // v_mfma_f32_32x32x16_bf16 per 32-channel block instead of eight v_mfma_f32_32x32x2_f32, the A planes faked from the
+    // fp32 fragments that are loaded anyway (a real kernel would load 1.5x the A bytes): an upper bound on what the
+    // verdict's opt-in item 5 can buy in this kernel structure.
+    {
+      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+      const float bx[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      bf16x8_t bh, bm, bl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)bx[j];
+        const float r = bx[j] - (float)h;
+        const __bf16 m = (__bf16)r;
+        const __bf16 l = (__bf16)(r - (float)m);
+        bh[j] = h; bm[j] = m; bl[j] = l;
+      }
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, ra[i][0]);
+        const bf16x8_t am = __builtin_bit_cast(bf16x8_t, ra[i][1]);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, fresh ? zero : acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bl, acc[i], 0, 0, 0);
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
