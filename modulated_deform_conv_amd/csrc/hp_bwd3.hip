@@ -333,8 +333,19 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     } else
 #endif
     if (one_img) {   // scalar row base, dead pixels out of range (dropped)
+#if defined(ABL_STORE_L2)    // developer ablation (timing only): both rows stored, into a 1 MB region that never leaves the L2
+      buf_store4u_nt(r_gcol, (tail.x & 0xfff00) + oc8 * 16, 0, gq);
+      buf_store4u_nt(r_col, (tail.x & 0xfff00) + oc8 * 16, 0, cq);
+#elif defined(ABL_STORE_GQ_ONLY)   // ... only the grad_col rows / only the column rows
+      buf_store4u_nt(r_gcol, tail.x + oc8 * 16, 0, gq);
+      if (cq.x == 0x12345678u && gq.y == 0x9abcdef0u) buf_store4u_nt(r_col, tail.x + oc8 * 16, 0, cq);
+#elif defined(ABL_STORE_CQ_ONLY)
+      buf_store4u_nt(r_col, tail.x + oc8 * 16, 0, cq);
+      if (cq.x == 0x12345678u && gq.y == 0x9abcdef0u) buf_store4u_nt(r_gcol, tail.x + oc8 * 16, 0, gq);
+#else
       buf_store4u_nt(r_gcol, tail.x + oc8 * 16, 0, gq);
       buf_store4u_nt(r_col, tail.x + oc8 * 16, 0, cq);
+#endif
     } else if (tail.x != kHpOob) {
       const size_t e = (size_t)tail.y * gcol_img + (tail.x >> 1) + oc8 * 8;
       *reinterpret_cast<U4 *>(gcol + e) = gq;
