@@ -32,43 +32,9 @@ __global__ __launch_bounds__(256) void hp_zero_int_kernel(int *__restrict__ p, i
 // segments).  A workgroup first sums everything before its chunk (the counters are L2-resident and
 // that is at most S reads), then scans its chunk -- one workgroup per SEGMENT, as in round 1, left
 // 8 workgroups walking 35 k anchors each at the 3-D shards (0.12 / 0.22 ms at cfg4 / cfg5).
-constexpr int kScanChunk = 2048;
 __global__ __launch_bounds__(256) void hp_csr_scan_kernel(int S, const int *__restrict__ cnt,
                                             int *__restrict__ rowptr) {
-  __shared__ int wsum[4];
-  __shared__ int carry;
-  const int seg = blockIdx.y;
-  const int lo = blockIdx.x * kScanChunk, hi = min(lo + kScanChunk, S);
-  const int *c = cnt + (int64_t)seg * S;
-  int *rp = rowptr + (int64_t)seg * (S + 1);
-  int pre = 0;
-  for (int i = threadIdx.x; i < lo; i += 256) pre += c[i];
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = pre;
-  __syncthreads();
-  if (threadIdx.x == 0) carry = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  __syncthreads();
-  for (int base = lo; base < hi; base += 256) {
-    const int i = base + threadIdx.x;
-    const int v = i < hi ? c[i] : 0;
-    int x = v;   // inclusive scan inside the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int y = __shfl_up(x, d, 64);
-      if ((threadIdx.x & 63) >= d) x += y;
-    }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-    __syncthreads();
-    int woff = 0;
-    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) woff += wsum[k];
-    const int excl = carry + woff + x - v;
-    if (i < hi) rp[i] = excl;
-    __syncthreads();
-    if (threadIdx.x == 255) carry = excl + v;
-    __syncthreads();
-  }
-  if (hi == S && threadIdx.x == 0) rp[S] = carry;
+  csr_scan_chunk(S, cnt, rowptr);   // mdconv_common.hpp
 }
 
 // Long entry = 2 x int4, fp32 fields: (src, wx, wy, rl0), (rh0, rl1, rh1, anchor)  [2-D: rl1 = rl0, rh1 = rh0].

@@ -332,6 +332,65 @@ __device__ __forceinline__ void sample_anchor(const Geom &g, const TapCoef<ND, f
   sa.on = on;
 }
 
+// ---- exclusive scan of the scatter-list counters (shared by csr_scan_kernel and hp_csr_scan_kernel) ----
+// cnt[seg][0..S) -> rowptr[seg][0..S]; grid (chunks of kScanChunk elements, segments), 256 threads.  A workgroup first sums
+// everything before its chunk (the counters are L2-resident, at most S coalesced reads, eight loads in flight), then scans
+// its chunk in ONE pass: thread t holds elements lo + 256 j + t (j = 0..7), the eight wave scans run as independent chains,
+// one barrier publishes the 8 x 4 wave totals.  (Rounds 1-5 walked the chunk 256 elements at a time behind three barriers
+// each: 45-70 us for the 8-64 workgroups of a cfg2 shard, on the critical path of the forked gather branch.)
+constexpr int kScanChunk = 2048;
+__device__ __forceinline__ void csr_scan_chunk(int S, const int *__restrict__ cnt, int *__restrict__ rowptr) {
+  __shared__ int wtot[8][4];
+  __shared__ int wpre[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int seg = blockIdx.y;
+  const int lo = blockIdx.x * kScanChunk, hi = min(lo + kScanChunk, S);
+  const int *c = cnt + (int64_t)seg * S;
+  int *rp = rowptr + (int64_t)seg * (S + 1);
+  int v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = lo + j * 256 + tid;
+    v[j] = i < hi ? c[i] : 0;
+  }
+  int pre = 0;
+  for (int i0 = tid; i0 < lo; i0 += 8 * 256) {
+    int a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = i0 + u * 256 < lo ? c[i0 + u * 256] : 0;
+    pre += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
+  int x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = v[j];
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int y = __shfl_up(x[j], d, 64);
+      if (lane >= d) x[j] += y;
+    }
+  }
+  if (lane == 63) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wtot[j][w] = x[j];
+  }
+  if (lane == 0) wpre[w] = pre;
+  __syncthreads();
+  int running = (wpre[0] + wpre[1]) + (wpre[2] + wpre[3]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int t0 = wtot[j][0], t1 = wtot[j][1], t2 = wtot[j][2], t3 = wtot[j][3];
+    const int woff = (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0);
+    const int i = lo + j * 256 + tid;
+    if (i < hi) rp[i] = running + woff + x[j] - v[j];
+    running += (t0 + t1) + (t2 + t3);
+  }
+  if (hi == S && tid == 0) rp[S] = running;
+}
+
 // ---- host-side helpers ------------------------------------------------------------------------
 int fill_geom(const mdconv_desc *d, Geom *g);  // validates; returns MDCONV_* code
 void set_error(const char *fmt, ...);

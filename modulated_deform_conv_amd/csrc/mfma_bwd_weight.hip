@@ -240,6 +240,12 @@ __global__ __launch_bounds__(256) void reduce_weight_kernel(Geom g, BwdDims bd,
     const size_t stride = (size_t)g.K * bd.OgpB * bd.Cp;
     float s = 0.f;
     int sp = 0;
+    for (; sp + 8 <= bd.splits; sp += 8) {   // eight partials in flight (beside the forked gather a load takes microseconds)
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(sp + u) * stride];
+      s += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     for (; sp + 4 <= bd.splits; sp += 4) {
       const float a0 = src[(size_t)sp * stride], a1 = src[(size_t)(sp + 1) * stride];
       const float a2 = src[(size_t)(sp + 2) * stride], a3 = src[(size_t)(sp + 3) * stride];
@@ -264,8 +270,17 @@ __global__ __launch_bounds__(256) void grad_bias_stage1_kernel(Geom g, int tiles
   const int o = blockIdx.x * 64 + (threadIdx.x & 63);
   const int quarter = threadIdx.x >> 6;
   float s = 0.f;
-  if (o < g.O)
-    for (int k = blockIdx.y * 4 + quarter; k < tiles; k += 4 * kBiasSlices) s += partial[(size_t)k * g.O + o];
+  if (o < g.O) {
+    // four partials in flight, added in a fixed order (a plain loop waited for one load per addition: 27 us at cfg2)
+    constexpr int kStep = 4 * kBiasSlices;
+    int k = blockIdx.y * 4 + quarter;
+    for (; k + 3 * kStep < tiles; k += 4 * kStep) {
+      const float a0 = partial[(size_t)k * g.O + o], a1 = partial[(size_t)(k + kStep) * g.O + o];
+      const float a2 = partial[(size_t)(k + 2 * kStep) * g.O + o], a3 = partial[(size_t)(k + 3 * kStep) * g.O + o];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; k < tiles; k += kStep) s += partial[(size_t)k * g.O + o];
+  }
   red[quarter][threadIdx.x & 63] = s;
   __syncthreads();
   if (quarter == 0 && o < g.O)
