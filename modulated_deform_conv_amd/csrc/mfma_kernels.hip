@@ -723,7 +723,12 @@ bool split_plan(const Geom &g, int dtype, SplitPlan *p) {
   take(p->off_gm, g.modulated ? (size_t)g.B * g.K * g.S_o : 0);
   take(p->off_gw, p->copy_w ? (size_t)s.O * s.Cg * g.K : 0);
   p->off_sub = off;
-  p->sub_bytes = native_workspace_bytes(s, dtype, true);
+  // sized for the slice WITH bias: the first slice of a conv group runs with with_bias = 1 (split_backward) and then
+  // has the grad_bias stage buffer at the end of its layout -- sized without it, that slice wrote 32 * C_out * 4 bytes
+  // past the workspace (found by tools/fuzz_more.py in round 5; tests/test_gpu_workspace_guard.py)
+  Geom sb = s;
+  sb.with_bias = g.with_bias;
+  p->sub_bytes = native_workspace_bytes(sb, dtype, true);
   p->total = off + p->sub_bytes;
   return true;
 }

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Extended random-shape campaign (developer aid, run on the GPU box): more seeds than tests/test_gpu_fuzz.py and MID-SIZE
+extents (several 32-pixel tiles, ragged tile tails, batch tails), where the small fuzz shapes of the suite end.
+  fp32:   matrix-core path against the shape-generic path (two independent implementations), every 4th shape also
+          against the CPU oracle;    16-bit: native kernels against the oracle on the fp16 / bf16-rounded inputs.
+usage: python tools/fuzz_more.py [--seconds 420] [--first 100]      prints one line per failure and a summary."""
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from tests.cases import D2, D3, M2, M3, _c, make_inputs  # noqa: E402
+from tests.util import assert_close, run_oracle, run_product  # noqa: E402
+
+
+def case_f32(seed):
+    r = random.Random(77000 + seed)
+    nd = r.choice([2, 2, 3])
+    modulated = r.random() < 0.6
+    op = {(2, False): D2, (2, True): M2, (3, False): D3, (3, True): M3}[(nd, modulated)]
+    groups = r.choice([1, 1, 1, 2, 4])
+    dg = r.choice([1, 1, 1, 2, 4])
+    if dg > 1:
+        C = dg * r.choice([16, 32, 64, 128])
+        while C % groups:
+            groups //= 2
+    else:
+        C = r.choice([16, 24, 32, 48, 64, 72, 96, 128, 136, 192, 256])
+        while C % groups:
+            groups = max(1, groups // 2)
+    O = r.choice([16, 17, 32, 33, 48, 64, 80, 128, 130, 256])
+    O = (O + groups - 1) // groups * groups
+    k = r.choice([1, 2, 3, 3, 3]) if nd == 2 else r.choice([1, 2, 3, 3])
+    stride = r.choice([1, 1, 2])
+    dil = r.choice([1, 1, 2])
+    pad = r.choice([0, 1, dil * (k - 1) // 2 + (1 if k > 1 else 0)])
+    lo = dil * (k - 1) + 1
+    hi = 40 if nd == 2 else 14
+    size = tuple(r.randint(max(lo, 3), hi) for _ in range(nd))
+    B = r.choice([1, 2, 3, 5])
+    return _c("more%d" % seed, op, B, C, O, size, k, stride=stride, padding=pad, dilation=dil, groups=groups, dgroups=dg,
+              in_step=r.choice([1, 64]), bias=r.random() < 0.5, tier="medium", seed=7000 + seed,
+              offset_scale=r.choice([0.5, 1.0, 3.0]))
+
+
+def case_hp(seed):
+    r = random.Random(88000 + seed)
+    nd = r.choice([2, 2, 3])
+    modulated = r.random() < 0.6
+    op = {(2, False): D2, (2, True): M2, (3, False): D3, (3, True): M3}[(nd, modulated)]
+    dg = r.choice([1, 1, 1, 2, 4, 8])
+    if dg > 1:
+        C = min(256, dg * r.choice([32, 64]))
+        dg = C // r.choice([c for c in (32, 64) if C % c == 0])
+        groups = r.choice([1, 2])
+    else:
+        C = r.choice([8, 24, 32, 40, 64, 96, 128, 136, 256])
+        groups = r.choice([1, 1, 1, 2, 4, 8])
+        while C % groups:
+            groups //= 2
+    O = r.choice([8, 24, 32, 48, 64, 100, 128, 200, 256])
+    O = (O + groups - 1) // groups * groups
+    k = r.choice([1, 2, 3, 3]) if nd == 2 else r.choice([1, 2, 3])
+    stride = r.choice([1, 1, 2])
+    dil = r.choice([1, 1, 2])
+    pad = r.choice([0, 1, dil * (k - 1) // 2 + (1 if k > 1 else 0)])
+    lo = dil * (k - 1) + 1
+    hi = 28 if nd == 2 else 10
+    size = tuple(r.randint(max(lo, 3), hi) for _ in range(nd))
+    size = size[:-1] + (max(size[-1], 2),)
+    return _c("morehp%d" % seed, op, r.choice([1, 2, 3]), C, O, size, k, stride=stride, padding=pad, dilation=dil,
+              groups=groups, dgroups=dg, in_step=64, bias=r.random() < 0.5, tier="medium", seed=8000 + seed,
+              offset_scale=r.choice([0.5, 1.0, 3.0]))
+
+
+def check(name, fn):
+    try:
+        fn()
+        return True
+    except AssertionError as e:
+        print("FAIL %s: %s" % (name, str(e).split("\n")[0][:300]), flush=True)
+        return False
+
+
+def main():
+    seconds, first = 420.0, 100
+    a = sys.argv[1:]
+    if "--seconds" in a:
+        seconds = float(a[a.index("--seconds") + 1])
+    if "--first" in a:
+        first = int(a[a.index("--first") + 1])
+    verbose = "--verbose" in a
+    t0 = time.time()
+    n = [0, 0, 0]
+    bad = 0
+    paths = {}
+    seed = first
+    while time.time() - t0 < seconds:
+        # ---- fp32: matrix path vs generic path (vs oracle every 4th) ----
+        case = case_f32(seed)
+        if verbose:
+            print("run", case, flush=True)
+        t = make_inputs(case, device="cuda")
+        out_a, g_a, p = run_product(case, t, "auto")
+        if verbose:
+            torch.cuda.synchronize(); print("  auto done", p, flush=True)
+        paths[tuple(p)] = paths.get(tuple(p), 0) + 1
+        out_d, g_d, _ = run_product(case, t, "direct")
+        if verbose:
+            torch.cuda.synchronize(); print("  direct done", flush=True)
+
+        def cmp32():
+            assert_close("output", out_a, out_d, 1e-4)
+            for k, v in g_a.items():
+                if v is not None and g_d[k] is not None:
+                    assert_close(k, v, g_d[k], 1e-4)
+        ok = check("%s %s" % (case["name"], {k: case[k] for k in ("op", "B", "C", "O", "in_sz", "k", "stride", "padding", "dilation", "groups", "dgroups")}), cmp32)
+        n[0] += 1
+        if seed % 4 == 0 and case["B"] * case["C"] * case["O"] < 200000:
+            want_out, want = run_oracle(case, t, torch.float32)
+
+            def cmpo():
+                assert_close("output/oracle", out_a, want_out, 1e-4)
+                for k, v in g_a.items():
+                    if v is not None and want[k] is not None:
+                        assert_close(k + "/oracle", v, want[k], 1e-4)
+            ok = check(case["name"] + " oracle", cmpo) and ok
+            n[1] += 1
+        bad += 0 if ok else 1
+        # ---- 16-bit vs oracle ----
+        dtype = torch.bfloat16 if seed % 3 == 0 else torch.float16
+        case = case_hp(seed)
+        if verbose:
+            print("run", dtype, case, flush=True)
+        t = make_inputs(case, dtype=dtype, device="cuda")
+        out, grads, p = run_product(case, t, "auto")
+        paths[("16", ) + tuple(p)] = paths.get(("16", ) + tuple(p), 0) + 1
+        want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
+        tol = 1e-2 if dtype == torch.float16 else 4e-2
+
+        def cmp16():
+            assert_close("output", out.float(), want_out, tol)
+            for k, v in grads.items():
+                if v is not None and want[k] is not None:
+                    assert_close(k, v.float(), want[k], tol)
+        ok = check("%s %s %s" % (case["name"], dtype, {k: case[k] for k in ("op", "B", "C", "O", "in_sz", "k", "stride", "padding", "dilation", "groups", "dgroups")}), cmp16)
+        n[2] += 1
+        bad += 0 if ok else 1
+        seed += 1
+    print("fuzz_more: seeds %d..%d, %d fp32 shapes (matrix vs generic path), %d of them also vs the oracle, %d 16-bit shapes vs the oracle; "
+          "%d FAILED; kernel paths %s; %.0f s" % (first, seed - 1, n[0], n[1], n[2], bad, paths, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
