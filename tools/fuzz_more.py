@@ -39,7 +39,13 @@ def case_f32(seed):
     lo = dil * (k - 1) + 1
     hi = 40 if nd == 2 else 14
     size = tuple(r.randint(max(lo, 3), hi) for _ in range(nd))
-    B = r.choice([1, 2, 3, 5])
+    B = r.choice([1, 2, 3, 5, 9])
+    if r.random() < 0.25:   # per-axis parameters
+        k = tuple(r.choice([1, 2, 3]) for _ in range(nd))
+        stride = tuple(r.choice([1, 2, 3]) for _ in range(nd))
+        dil = tuple(r.choice([1, 2]) for _ in range(nd))
+        pad = tuple(r.choice([0, 1, 2]) for _ in range(nd))
+        size = tuple(max(sz, d_ * (k_ - 1) + 1) for sz, d_, k_ in zip(size, dil, k))
     return _c("more%d" % seed, op, B, C, O, size, k, stride=stride, padding=pad, dilation=dil, groups=groups, dgroups=dg,
               in_step=r.choice([1, 64]), bias=r.random() < 0.5, tier="medium", seed=7000 + seed,
               offset_scale=r.choice([0.5, 1.0, 3.0]))
@@ -73,6 +79,60 @@ def case_hp(seed):
     return _c("morehp%d" % seed, op, r.choice([1, 2, 3]), C, O, size, k, stride=stride, padding=pad, dilation=dil,
               groups=groups, dgroups=dg, in_step=64, bias=r.random() < 0.5, tier="medium", seed=8000 + seed,
               offset_scale=r.choice([0.5, 1.0, 3.0]))
+
+
+GUARD = 1 << 16
+_guards = []
+
+
+def guarded_zeros(like):
+    """A zero tensor of `like`'s shape / dtype in the middle of a pattern-filled allocation (checked by guards_clean)."""
+    n = like.numel() * like.element_size()
+    big = torch.full((n + 2 * GUARD,), 0xA5, dtype=torch.uint8, device=like.device)
+    view = big[GUARD:GUARD + n].view(like.dtype).view(like.shape)
+    view.zero_()
+    _guards.append((big, n))
+    return view
+
+
+def guards_clean():
+    torch.cuda.synchronize()
+    bad = []
+    for big, n in _guards:
+        for side, reg in (("below", big[:GUARD]), ("above", big[GUARD + n:])):
+            if bool((reg != 0xA5).any()):
+                bad.append("%d-byte tensor: written %s" % (n, side))
+    _guards.clear()
+    return bad
+
+
+def run_guarded_outputs(case, t):
+    """The caller-allocated outputs of the DCN2d / DCN3d / MDCN3d entry points with guard margins (the MDCN2d entry
+    points allocate their own results).  Returns the list of violated margins."""
+    from tests.cases import ndim
+    from tests.util import tup
+    from modulated_deform_conv_amd import MDCONV_CUDA as M
+    op, nd = case["op"], ndim(case)
+    if op == M2:
+        return []
+    k, s_, p, d = (tup(case[x], nd) for x in ("k", "stride", "padding", "dilation"))
+    geo = k + s_ + p + d + (case["groups"], case["dgroups"], case["in_step"], case["bias"])
+    x, w, off, m, go = t["input"], t["weight"], t["offset"], t["mask"], t["grad_output"]
+    b = t["bias"] if case["bias"] else x.new_empty(0)
+    out = guarded_zeros(go)
+    gi, gw, goff = guarded_zeros(x), guarded_zeros(w), guarded_zeros(off)
+    gb = guarded_zeros(b) if case["bias"] else torch.zeros_like(b)
+    if op == D2:
+        M.deform_conv2d_forward_cuda(x, w, b, off, out, *geo)
+        M.deform_conv2d_backward_cuda(x, w, b, off, gi, gw, gb, goff, go, *geo)
+    elif op == D3:
+        M.deform_conv3d_forward_cuda(x, w, b, off, out, *geo)
+        M.deform_conv3d_backward_cuda(x, w, b, off, gi, gw, gb, goff, go, *geo)
+    else:
+        gm = guarded_zeros(m)
+        M.modulated_deform_conv3d_forward_cuda(x, w, b, off, m, out, *geo)
+        M.modulated_deform_conv3d_backward_cuda(x, w, b, off, m, gi, gw, gb, goff, gm, go, *geo)
+    return guards_clean()
 
 
 def check(name, fn):
@@ -118,6 +178,10 @@ def main():
                     assert_close(k, v, g_d[k], 1e-4)
         ok = check("%s %s" % (case["name"], {k: case[k] for k in ("op", "B", "C", "O", "in_sz", "k", "stride", "padding", "dilation", "groups", "dgroups")}), cmp32)
         n[0] += 1
+        viol = run_guarded_outputs(case, t)
+        if viol:
+            print("FAIL %s guard margins of caller tensors: %s" % (case["name"], viol), flush=True)
+            ok = False
         if seed % 4 == 0 and case["B"] * case["C"] * case["O"] < 200000:
             want_out, want = run_oracle(case, t, torch.float32)
 
@@ -147,6 +211,10 @@ def main():
                     assert_close(k, v.float(), want[k], tol)
         ok = check("%s %s %s" % (case["name"], dtype, {k: case[k] for k in ("op", "B", "C", "O", "in_sz", "k", "stride", "padding", "dilation", "groups", "dgroups")}), cmp16)
         n[2] += 1
+        viol = run_guarded_outputs(case, t)
+        if viol:
+            print("FAIL %s %s guard margins of caller tensors: %s" % (case["name"], dtype, viol), flush=True)
+            ok = False
         bad += 0 if ok else 1
         seed += 1
     print("fuzz_more: seeds %d..%d, %d fp32 shapes (matrix vs generic path), %d of them also vs the oracle, %d 16-bit shapes vs the oracle; "
