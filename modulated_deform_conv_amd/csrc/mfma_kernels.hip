@@ -158,6 +158,11 @@ BwdDims bwd_dims(const Geom &g) {
             bd.wtile, col_tiles, occ, slots, bd.splits, bd.pairs_per_split);
   bd.ochunks = (g.O + 63) / 64 * 4;   // K loop of GEMM-1 is unrolled 4x
   bd.waves_c = g.C > 128 ? 4 : (g.C > 64 ? 2 : 1);
+  // The grad_out tile ([32 * 4 / waves_c pixels] x C_out) lives in LDS: when it does not fit with the natural wave split
+  // (C_in <= 64 and C_out > ~192 in 3-D: 128 pixels x 256 channels = 133 KB + the drain's tiles), more waves go along the
+  // channels -- the extra ones own zero-padded channel blocks and idle through the drain -- and the pixel tile shrinks
+  // with them.  Half the matrix rate of GEMM-1 at such shapes, against the shape-generic kernels they used to fall to (~10x).
+  for (;;) {
   bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
   // GEMM-1 drain: channels-last (line-wide gathers through an LDS hand-over, mfma_bwd_data.hip)
   // whenever the backward has the channels-last copy -- except for straight-line 2-D shapes whose
@@ -185,6 +190,9 @@ BwdDims bwd_dims(const Geom &g) {
       bd.cl_drain = 0;
       size_red();
     }
+  }
+  if (bwd_data_lds_bytes(g, bd) <= 150 * 1024 || bd.waves_c == 4) break;
+  bd.waves_c *= 2;
   }
   const int nc = 1 << g.nd;
   size_t off = 0;

@@ -62,6 +62,12 @@ CASES = [
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),
+    # grad_out tile too large for LDS with the natural wave split (C_in <= 64, wide C_out): GEMM-1 puts more waves along the
+    # channels (zero-padded blocks) instead of leaving the shape to the shape-generic kernels (round 5, bwd_dims)
+    _c("mfma_mdcn3d_c64_o256_lds", M3, 1, 64, 256, (5, 6, 5), 3, tier="medium", seed=39),
+    _c("mfma_dcn3d_c32_o320_g1_lds", D3, 2, 32, 320, (4, 5, 6), 3, bias=False, tier="medium", seed=40),
+    _c("mfma_dcn2d_c64_o640_lds", D2, 2, 64, 640, (9, 8), 3, in_step=1, tier="medium", seed=46),
+    _c("mfma_mdcn3d_c128_dg2_o512_lds", M3, 1, 128, 512, (4, 5, 5), 3, dgroups=2, tier="medium", seed=47),
     # kernel shapes / strides the MFMA kernels must also get right: 1x1, 5x5 stride 2 (25 taps =
     # three tap groups), rectangular, large dilation, anisotropic 3-D
     _c("mfma_mdcn2d_k1_c64_o32", M2, 2, 64, 32, (9, 11), 1, padding=0, tier="medium", seed=41),

@@ -106,6 +106,28 @@ def guards_clean():
     return bad
 
 
+def nan_margined(t):
+    """Copies of the input tensors, each in the middle of a NaN-filled allocation: a read past either end of a tensor that
+    enters the arithmetic (0 * NaN included) shows up as NaN in the results."""
+    out = {}
+    for name, v in t.items():
+        if v is None:
+            out[name] = None
+            continue
+        pad = GUARD // v.element_size()
+        big = torch.full((v.numel() + 2 * pad,), float("nan"), dtype=v.dtype, device=v.device)
+        view = big[pad:pad + v.numel()].view(v.shape)
+        view.copy_(v)
+        out[name] = view
+    return out
+
+
+def all_finite(out, grads):
+    bad = [] if bool(torch.isfinite(out.float()).all()) else ["output"]
+    bad += [k for k, v in grads.items() if v is not None and not bool(torch.isfinite(v.float()).all())]
+    return bad
+
+
 def run_guarded_outputs(case, t):
     """The caller-allocated outputs of the DCN2d / DCN3d / MDCN3d entry points with guard margins (the MDCN2d entry
     points allocate their own results).  Returns the list of violated margins."""
@@ -162,7 +184,7 @@ def main():
         case = case_f32(seed)
         if verbose:
             print("run", case, flush=True)
-        t = make_inputs(case, device="cuda")
+        t = nan_margined(make_inputs(case, device="cuda"))
         out_a, g_a, p = run_product(case, t, "auto")
         if verbose:
             torch.cuda.synchronize(); print("  auto done", p, flush=True)
@@ -172,6 +194,8 @@ def main():
             torch.cuda.synchronize(); print("  direct done", flush=True)
 
         def cmp32():
+            assert not all_finite(out_a, g_a), "matrix path: NaN from a read outside a tensor: %s" % all_finite(out_a, g_a)
+            assert not all_finite(out_d, g_d), "generic path: NaN from a read outside a tensor: %s" % all_finite(out_d, g_d)
             assert_close("output", out_a, out_d, 1e-4)
             for k, v in g_a.items():
                 if v is not None and g_d[k] is not None:
@@ -198,13 +222,14 @@ def main():
         case = case_hp(seed)
         if verbose:
             print("run", dtype, case, flush=True)
-        t = make_inputs(case, dtype=dtype, device="cuda")
+        t = nan_margined(make_inputs(case, dtype=dtype, device="cuda"))
         out, grads, p = run_product(case, t, "auto")
         paths[("16", ) + tuple(p)] = paths.get(("16", ) + tuple(p), 0) + 1
         want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
         tol = 1e-2 if dtype == torch.float16 else 4e-2
 
         def cmp16():
+            assert not all_finite(out, grads), "16-bit path: NaN from a read outside a tensor: %s" % all_finite(out, grads)
             assert_close("output", out.float(), want_out, tol)
             for k, v in grads.items():
                 if v is not None and want[k] is not None:
