@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void fwd_tail_reduce_kernel(Geom g, const floa
   }
 }
 
-constexpr int kTailMaxPerCu = 5;   // resident workgroups per CU the tail plan and its scratch are sized for
+}  // namespace
 
 // Tail plan of a tile grid (see the kernel): `full` tiles run whole, the others -- the leftover of the last dispatch
 // round, or every tile of a grid smaller than one round -- are cut into tap ranges so that the round is FULL: with
@@ -443,6 +443,22 @@ void fwd_tail_plan(const Geom &g, int tiles, int slots, int *full_tiles, int *wa
   *n_hi = hi;
 }
 
+int fwd_tail_reduce_launch(int BM, int BN, const Geom &g, const float *part, const float *bias, float *output, int ntm,
+                           int tail_tiles, int full_tiles, int ways, int n_hi, hipStream_t stream) {
+  if (tail_tiles <= 0) return MDCONV_OK;
+#define FWD_TAIL_RED(M, N)                                                                                        \
+  hipLaunchKernelGGL((fwd_tail_reduce_kernel<M, N>), dim3(tail_tiles, kTailSlices), dim3(256), 0, stream, g, part, bias, \
+                     output, ntm, full_tiles, ways, n_hi)
+  if (BM == 256 && BN == 32) FWD_TAIL_RED(256, 32);
+  else if (BM == 128 && BN == 64) FWD_TAIL_RED(128, 64);
+  else if (BM == 64 && BN == 128) FWD_TAIL_RED(64, 128);
+  else if (BM == 64 && BN == 64) FWD_TAIL_RED(64, 64);
+  else { set_error("fwd_tail_reduce: no instance for a %d x %d tile", BM, BN); return MDCONV_ELAUNCH; }
+#undef FWD_TAIL_RED
+  return check_launch("fwd_tail_reduce");
+}
+
+namespace {
 template <int ND, bool MOD, int BM, int BN, int WM, int WN, bool PADK>
 int fwd_tile_slots() {
   static int slots = 0;
@@ -477,9 +493,8 @@ int launch_fwd_tile_k(const Geom &g, const PackDims &pd, const Tensors &t, const
                      full_tiles, ways, n_hi, part);
   int rc = check_launch("mfma_fwd");
   if (rc || tail_tiles == 0) return rc;
-  hipLaunchKernelGGL((fwd_tail_reduce_kernel<BM, BN>), dim3(tail_tiles, kTailSlices), dim3(256), 0, stream, g, part,
-                     (const float *)t.bias, (float *)t.output, ntm, full_tiles, ways, n_hi);
-  return check_launch("fwd_tail_reduce");
+  return fwd_tail_reduce_launch(BM, BN, g, part, (const float *)t.bias, (float *)t.output, ntm, tail_tiles, full_tiles, ways,
+                                n_hi, stream);
 }
 
 template <int ND, bool MOD, int BM, int BN, int WM, int WN>

@@ -22,6 +22,7 @@
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace mdconv {
@@ -45,7 +46,8 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
                                                              const float *__restrict__ offset,
                                                              const float *__restrict__ mask,
                                                              float *__restrict__ output, int ntm,
-                                                             int ntn) {
+                                                             int ntn, int full_tiles, int tail_ways, int tail_hi,
+                                                             float *__restrict__ part) {
   constexpr int NC = 1 << ND;
   constexpr int MB = WM / 32;
   constexpr int WAVES_M = BM / WM, WAVES_N = 4 / WAVES_M;
@@ -57,7 +59,31 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
   __shared__ __attribute__((aligned(16))) float St[3 * BN * SW];
 
   const int grp = blockIdx.y;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  // Blocks [0, full_tiles) own a whole tile; the tiles left over (the last, partly filled dispatch round -- or every tile of a
+  // grid smaller than one round) are cut into tap ranges, each block writing its partial tile to `part`
+  // (fwd_tail_plan / fwd_tail_reduce_launch, mfma_fwd.hip: the same plan as the NCHW forward).  Round 5: a 3-D forward of a
+  // few tiles used to take one whole-tile time (27 taps on an otherwise empty chip) whatever its size.
+  int tile, tap_lo = 0, tap_hi = g.K, tail_slot = -1;
+  if ((int)blockIdx.x < full_tiles) {
+    tile = xcd_remap(blockIdx.x, full_tiles);
+  } else {
+    tail_slot = blockIdx.x - full_tiles;
+    const int hi_slots = tail_hi * (tail_ways + 1);
+    int ti, way, wt;
+    if (tail_slot < hi_slots) {
+      wt = tail_ways + 1;
+      ti = tail_slot / wt;
+      way = tail_slot - ti * wt;
+    } else {
+      wt = tail_ways;
+      const int r = tail_slot - hi_slots;
+      ti = tail_hi + r / wt;
+      way = r - (r / wt) * wt;
+    }
+    tile = full_tiles + ti;
+    tap_lo = way * g.K / wt;
+    tap_hi = (way + 1) * g.K / wt;
+  }
   const int tn = tile / ntm, tm = tile - tn * ntm;
   const int o0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
@@ -66,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
   const int cq = tid & 15, pg = tid >> 4;   // channel quad of the slab, pixel group
 
   const int spt = g.Cg / kSlab;             // slabs per tap
-  const int S = g.K * spt;
+  const int S = (tap_hi - tap_lo) * spt;
   const int cchunks = pd.Cgp / kBK;
   const int mblks = pd.Ogp / 32;
   const int slab_bytes = mblks * 2 * 64 * 16;   // one 16-channel chunk of packed weights
@@ -165,26 +191,26 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
       }
   };
 
-  // ---- prologue: states of taps 0 and 1, slab 0 into Bs[0] ----
-  fetch_tap(0);
-  build_state(0);
-  if (g.K > 1) {
-    fetch_tap(1);
-    build_state(1);
+  // ---- prologue: states of the first two taps of the range, slab 0 into Bs[0] ----
+  fetch_tap(tap_lo);
+  build_state(tap_lo);
+  if (tap_lo + 1 < tap_hi) {
+    fetch_tap(tap_lo + 1);
+    build_state(tap_lo + 1);
   }
-  if (g.K > 2) fetch_tap(2);   // consumed while the first slab is multiplied
+  if (tap_lo + 2 < tap_hi) fetch_tap(tap_lo + 2);   // consumed while the first slab is multiplied
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     Px px;
-    issue_px(px, 0, 0, pg + 16 * i);
-    commit_px(px, 0, pg + 16 * i, Bs);
+    issue_px(px, tap_lo, 0, pg + 16 * i);
+    commit_px(px, tap_lo, pg + 16 * i, Bs);
   }
   float4 ra0[MB][2], ra1[MB][2];
-  load_a(ra0, 0);
+  load_a(ra0, tap_lo * cchunks);
   __syncthreads();
 
-  int tap = 0, cs = 0;   // tap and slab-in-tap of slab s
+  int tap = tap_lo, cs = 0;   // tap and slab-in-tap of slab s
   for (int s = 0; s < S; ++s) {
     // slab s+1; after the last slab: a harmless repeat of slab s into the unused buffer
     int tapn = tap, csn = cs + 1;
@@ -215,8 +241,8 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
       if (j == 1 && cs == 0) {
         // first slab of a tap: build the state of tap + 2 (its offsets were requested one tap
         // ago) and request the offsets of tap + 3
-        if (tap + 2 < g.K) build_state(tap + 2);
-        if (tap + 3 < g.K) fetch_tap(tap + 3);
+        if (tap + 2 < tap_hi) build_state(tap + 2);
+        if (tap + 3 < tap_hi) fetch_tap(tap + 3);
       }
     }
     __syncthreads();
@@ -224,6 +250,14 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
     cs = csn;
   }
 
+  if (tail_slot >= 0) {   // partial tile of a tap range: part[tail_slot][o of the tile][pixel of the tile]
+    float *dst = part + (size_t)tail_slot * (BM * BN) + wn0 + (lane & 31);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(wm0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * BN] = acc[mb][r];
+    return;
+  }
   // ---- epilogue: + bias, store [B, O, S_o] (lanes 0-31 -> 32 consecutive pixels) ----
   const int n_e = n0 + wn0 + (lane & 31);
   if (n_e < g.N) {
@@ -244,21 +278,54 @@ __global__ __launch_bounds__(256, 2) void mfma_fwd_cl_kernel(Geom g, PackDims pd
 }
 
 template <int ND, bool MOD, int BM, int BN, int WM>
-int launch_cl(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, const float *xt,
+int launch_cl(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, const float *xt, float *part,
               hipStream_t stream) {
   const int ntm = (g.Og + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  hipLaunchKernelGGL((mfma_fwd_cl_kernel<ND, MOD, BM, BN, WM>), dim3(ntm * ntn, g.G), dim3(256), 0,
+  // resident slots of this instance (static LDS), clamped like the NCHW forward's: the tail scratch holds one partial
+  // tile per slot
+  static int slots = 0;
+  if (!slots) {
+    int n = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &n, reinterpret_cast<const void *>(&mfma_fwd_cl_kernel<ND, MOD, BM, BN, WM>), 256, 0);
+    (void)hipGetLastError();
+    int cus = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = (cus > 0 ? cus : 256) * (n > 0 ? (n < kTailMaxPerCu ? n : kTailMaxPerCu) : 2);
+  }
+  int full_tiles, ways, n_hi;
+  fwd_tail_plan(g, ntm * ntn, part ? slots : 0, &full_tiles, &ways, &n_hi);
+  {
+    // a range must keep enough 64-channel slabs to pay for its prologue, its partial tile and the reduction: with C_in = 64
+    // in 2-D a tile is 9 slabs, and halves of it measured 9 % SLOWER than whole tiles (C = 64, 56 x 56, B = 8: 51.5 -> 56.1 us)
+    const int most = ways + (n_hi > 0 ? 1 : 0);
+    if (most > 1 && (g.K / most) * (g.Cg / kSlab) < 6) {
+      full_tiles = ntm * ntn;
+      ways = 1;
+      n_hi = 0;
+    }
+  }
+  const int tail_tiles = ntm * ntn - full_tiles;
+  static const bool debug_plan = getenv("MDCONV_DEBUG_PLAN") != nullptr;
+  if (debug_plan)
+    fprintf(stderr, "[mdconv] forward plan (channels-last): %d x %d tile, %d tiles, slots %d, full %d, tail %d x %d tap ranges (%d of them x %d)\n",
+            BM, BN, ntm * ntn, part ? slots : 0, full_tiles, tail_tiles, ways, n_hi, ways + 1);
+  hipLaunchKernelGGL((mfma_fwd_cl_kernel<ND, MOD, BM, BN, WM>), dim3(full_tiles + tail_tiles * ways + n_hi, g.G), dim3(256), 0,
                      stream, g, pd, xt, wp, (const float *)t.bias, (const float *)t.offset,
-                     (const float *)t.mask, (float *)t.output, ntm, ntn);
-  return check_launch("mfma_fwd_cl");
+                     (const float *)t.mask, (float *)t.output, ntm, ntn, full_tiles, ways, n_hi, part);
+  const int rc = check_launch("mfma_fwd_cl");
+  if (rc || tail_tiles == 0) return rc;
+  return fwd_tail_reduce_launch(BM, BN, g, part, (const float *)t.bias, (float *)t.output, ntm, tail_tiles, full_tiles, ways,
+                                n_hi, stream);
 }
 
 template <int ND, bool MOD>
 int launch_cl_tiles(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
-                    const float *xt, hipStream_t stream) {
-  if (pd.BM == 256) return launch_cl<ND, MOD, 256, 32, 64>(g, pd, t, wp, xt, stream);
-  if (pd.BM == 128) return launch_cl<ND, MOD, 128, 64, 64>(g, pd, t, wp, xt, stream);
-  return launch_cl<ND, MOD, 64, 64, 32>(g, pd, t, wp, xt, stream);
+                    const float *xt, float *part, hipStream_t stream) {
+  if (pd.BM == 256) return launch_cl<ND, MOD, 256, 32, 64>(g, pd, t, wp, xt, part, stream);
+  if (pd.BM == 128) return launch_cl<ND, MOD, 128, 64, 64>(g, pd, t, wp, xt, part, stream);
+  return launch_cl<ND, MOD, 64, 64, 32>(g, pd, t, wp, xt, part, stream);
 }
 
 }  // namespace
@@ -296,15 +363,15 @@ int nchw_to_nhwc_f32(const Geom &g, const float *x, float *xt, hipStream_t strea
   return check_launch("nchw_to_nhwc");
 }
 
-int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,
                         float *xt, hipStream_t stream) {
   const int rc = nchw_to_nhwc_f32(g, (const float *)t.input, xt, stream);
   if (rc) return rc;
   if (g.nd == 2)
-    return g.modulated ? launch_cl_tiles<2, true>(g, pd, t, wp, xt, stream)
-                       : launch_cl_tiles<2, false>(g, pd, t, wp, xt, stream);
-  return g.modulated ? launch_cl_tiles<3, true>(g, pd, t, wp, xt, stream)
-                     : launch_cl_tiles<3, false>(g, pd, t, wp, xt, stream);
+    return g.modulated ? launch_cl_tiles<2, true>(g, pd, t, wp, xt, part, stream)
+                       : launch_cl_tiles<2, false>(g, pd, t, wp, xt, part, stream);
+  return g.modulated ? launch_cl_tiles<3, true>(g, pd, t, wp, xt, part, stream)
+                     : launch_cl_tiles<3, false>(g, pd, t, wp, xt, part, stream);
 }
 
 }  // namespace mdconv

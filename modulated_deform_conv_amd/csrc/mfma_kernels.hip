@@ -263,7 +263,7 @@ size_t core_bytes_for(const Geom &gc, bool backward) {
   const PackDims pd = pack_dims(gc);
   size_t n = align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float));
   if (fwd_channels_last(gc)) n += align_up(fwd_cl_bytes(gc));   // NHWC copy of the input chunk
-  else n += align_up(fwd_tail_bytes(gc));                       // tap-range partials of the last dispatch round
+  n += align_up(fwd_tail_bytes(gc));                            // tap-range partials of the last dispatch round
   return n;
 }
 
@@ -610,7 +610,8 @@ static int native_forward(const Geom &g, int dtype, const Tensors &t, void *ws, 
     profile_mark(0, true, stream, fwd_channels_last(gc) ? "mfma_fwd_cl_kernel" : "mfma_fwd_kernel");
     if (fwd_channels_last(gc)) {
       float *xt = (float *)(base + align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float)));
-      rc = mfma_forward_cl_f32(gc, pd, tc, wp, xt, stream);
+      float *part = (float *)((char *)xt + align_up(fwd_cl_bytes(gc)));
+      rc = mfma_forward_cl_f32(gc, pd, tc, wp, fwd_tail_bytes(gc) ? part : nullptr, xt, stream);
     } else {
       float *part = (float *)(base + align_up((size_t)gc.G * gc.K * pd.Cgp * pd.Ogp * sizeof(float)));
       rc = mfma_forward_f32(gc, pd, tc, wp, fwd_tail_bytes(gc) ? part : nullptr, stream);

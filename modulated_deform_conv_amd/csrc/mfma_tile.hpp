@@ -120,12 +120,18 @@ int pack_weights_f32(const Geom &g, const PackDims &pd, const float *weight, flo
                      hipStream_t stream);
 // part: scratch of fwd_tail_bytes(g) for the tap-range partials of the last dispatch round (nullptr = no tail split)
 size_t fwd_tail_bytes(const Geom &g);
+// tail plan of a forward tile grid and the reduction of its tap-range partials (mfma_fwd.hip; shared with the channels-last
+// forward of mfma_fwd_cl.hip): see fwd_tail_plan there
+constexpr int kTailMaxPerCu = 5;   // resident workgroups per CU the tail plan and its scratch are sized for
+void fwd_tail_plan(const Geom &g, int tiles, int slots, int *full_tiles, int *ways, int *n_hi);
+int fwd_tail_reduce_launch(int BM, int BN, const Geom &g, const float *part, const float *bias, float *output, int ntm,
+                           int tail_tiles, int full_tiles, int ways, int n_hi, hipStream_t stream);
 int mfma_forward_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,
                      hipStream_t stream);
 // channels-last gathers (mfma_fwd_cl.hip): xt = scratch for the NHWC copy of the input
 bool fwd_channels_last(const Geom &g);
 size_t fwd_cl_bytes(const Geom &g);
-int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp,
+int mfma_forward_cl_f32(const Geom &g, const PackDims &pd, const Tensors &t, const float *wp, float *part,
                         float *xt, hipStream_t stream);
 int mfma_bwd_weight_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *ga,
                         const int *table, float *part, const float *bias_part, const float *xt,
