@@ -197,6 +197,23 @@ bool hp_supported(const Geom &g, int dtype, bool backward) {
   return chunk_batch(g, hd, backward) > 0;
 }
 
+// Forward of a FEW pixel tiles over MANY K stages: hp_fwd2 runs one workgroup per (128-pixel tile, output-channel row)
+// through every tap and 64-channel stage, so a grid of a dozen workgroups takes one whole tile time on an otherwise empty
+// chip (C = 512, 7 x 7, B = 16: 231 us; 3-D C = 256, 4 x 7 x 7, B = 4: 547 us) -- whereas the fp32 matrix forwards cut such
+// grids into tap ranges (fwd_tail_plan) and take 87 / 109 us for the same shapes.  Such calls run on the fp32 kernels
+// through fp32 copies (the route of every 16-bit shape the native kernels do not take: fp32 accumulation, one rounding of
+// the output).  Not with a channels-last input (only the native kernels read it in place), not when MDCONV_HP_FWD selects a
+// kernel explicitly (the forced-path tests).
+bool hp_forward_preferred(const Geom &g, int dtype) {
+  static const bool forced = getenv("MDCONV_HP_FWD") != nullptr;
+  if (forced) return true;
+  const HpDims hd = hp_dims(g);
+  const long wgs = (long)((g.N + 127) / 128) * hd.oranges;
+  const long stages = (long)g.K * ((g.C + 63) / 64);
+  if (wgs > 16 || stages < 64) return true;
+  return !mfma_supported(g, dtype, false);
+}
+
 size_t hp_workspace_bytes(const Geom &g, int dtype, bool backward) {
   HpDims hd = hp_dims(g);
   const int bc = chunk_batch(g, hd, backward);

@@ -6,6 +6,8 @@ namespace mdconv {
 
 bool hp_supported(const Geom &g, int dtype, bool backward);
 size_t hp_workspace_bytes(const Geom &g, int dtype, bool backward);
+// false: a forward of a few pixel tiles over many K stages, faster on the fp32 matrix kernels through fp32 copies (hp_host.hip)
+bool hp_forward_preferred(const Geom &g, int dtype);
 int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
 int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream);
 

@@ -214,8 +214,9 @@ static int run_forward(const mdconv_desc *d, int nd, int modulated, Tensors t, v
     set_error("channels-last input is only supported by the native 16-bit kernels with C_in a multiple of 32");
     return MDCONV_EUNSUPPORTED;
   }
-  // 16-bit tensors: native fp16 / bf16 kernels (hp_*.hip) when the shape qualifies
-  if (path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, false)) {
+  // 16-bit tensors: native fp16 / bf16 kernels (hp_*.hip) when the shape qualifies (and is not one of the few-tile forwards
+  // that the fp32 kernels run faster: hp_forward_preferred)
+  if (path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, false) && (g.in_cl || hp_forward_preferred(g, d->dtype))) {
     if ((rc = check_ws(ws, ws_bytes, hp_workspace_bytes(g, d->dtype, false)))) return rc;
     g_last_path = MDCONV_PATH_MFMA;
     g_last_kernels = MDCONV_KERNELS_HP;
@@ -385,7 +386,14 @@ size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward) {
   const bool half = d->dtype == MDCONV_F16 || d->dtype == MDCONV_BF16;
   const size_t direct = backward && half ? direct16_workspace_bytes(g) : 0;   // fp32 copies for the scatter kernels
   if (current_path() == MDCONV_PATH_DIRECT) return direct;
-  if (hp_supported(g, d->dtype, backward != 0)) return hp_workspace_bytes(g, d->dtype, backward != 0);
+  if (hp_supported(g, d->dtype, backward != 0)) {
+    const size_t hp = hp_workspace_bytes(g, d->dtype, backward != 0);
+    if (backward || hp_forward_preferred(g, d->dtype)) return hp;
+    // a few-tile forward: fp32 kernels through fp32 copies, unless the input turns out to be channels-last (not known
+    // here): enough for either
+    const size_t f32 = mfma_workspace_bytes(g, d->dtype, false);
+    return hp > f32 ? hp : f32;
+  }
   if (!mfma_supported(g, d->dtype, backward != 0)) return direct;
   return mfma_workspace_bytes(g, d->dtype, backward != 0);
 }
