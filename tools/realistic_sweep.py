@@ -29,13 +29,14 @@ def main():
             for _ in range(2):
                 _, _, p = run_product(case, t, "auto")
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            n = 5
-            for _ in range(n):
+            times = []
+            for _ in range(7):   # median of single steps: one-off stalls (allocator growth, first use of an instance) do not count
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 run_product(case, t, "auto")
-            e1.record(); torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / n
+                e1.record(); torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1))
+            ms = sorted(times)[len(times) // 2]
             K = 9 if len(sz) == 2 else 27
             so = 1
             for v in out_size(case):
