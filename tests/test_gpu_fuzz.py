@@ -7,7 +7,7 @@ import random
 import pytest
 import torch
 
-from tests.cases import D2, D3, M2, M3, _c, make_inputs
+from tests.cases import D2, D3, M2, M3, _c, case_f32_wide, case_hp_wide, make_inputs
 from tests.util import assert_close, run_oracle, run_product
 
 pytestmark = pytest.mark.gpu
@@ -115,6 +115,42 @@ def test_16bit_random_shapes_against_the_oracle(seed, dtype):
     if dtype == torch.bfloat16 and seed % 3:
         pytest.skip("bf16: every third shape")
     case = _random_hp_case(seed)
+    t = make_inputs(case, dtype=dtype, device="cuda")
+    out, grads, _ = run_product(case, t, "auto")
+    want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
+    tol = 1e-2 if dtype == torch.float16 else 4e-2
+    assert_close("output", out.float(), want_out, tol)
+    for k, v in grads.items():
+        if v is not None and want[k] is not None:
+            assert_close(k, v.float(), want[k], tol)
+
+
+@pytest.mark.parametrize("seed", range(100, 132))
+def test_wide_geometry_fp32(seed):
+    """Kernel extents up to 7 (2-D) / 5 (3-D) per axis -- 16 to 125 taps, where the case list stops at 27 --, strides and
+    dilations up to 3, extents down to one output position, offsets of up to 8 pixels: matrix-core path against the generic
+    path, every second shape also against the oracle (campaign: profiles/r05_experiments.md 25, 4134 shapes clean)."""
+    case = case_f32_wide(seed)
+    t = make_inputs(case, device="cuda")
+    out_a, g_a, _ = run_product(case, t, "auto")
+    out_d, g_d, _ = run_product(case, t, "direct")
+    assert_close("output", out_a, out_d, 1e-4)
+    for k, v in g_a.items():
+        if v is not None and g_d[k] is not None:
+            assert_close(k, v, g_d[k], 1e-4)
+    if seed % 2 == 0 and case["B"] * case["C"] * case["O"] < 200000:
+        want_out, want = run_oracle(case, t, torch.float32)
+        assert_close("output/oracle", out_a, want_out, 1e-4)
+        for k, v in g_a.items():
+            if v is not None and want[k] is not None:
+                assert_close(k + "/oracle", v, want[k], 1e-4)
+
+
+@pytest.mark.parametrize("seed", range(100, 124))
+def test_wide_geometry_16bit(seed):
+    """The same geometry on the native 16-bit kernels against the oracle (fp16; every third shape bf16)."""
+    dtype = torch.bfloat16 if seed % 3 == 0 else torch.float16
+    case = case_hp_wide(seed)
     t = make_inputs(case, dtype=dtype, device="cuda")
     out, grads, _ = run_product(case, t, "auto")
     want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)

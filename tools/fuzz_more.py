@@ -13,7 +13,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from tests.cases import D2, D3, M2, M3, _c, make_inputs  # noqa: E402
+from tests.cases import D2, D3, M2, M3, _c, case_f32_wide, case_hp_wide, make_inputs  # noqa: E402
 from tests.util import assert_close, run_oracle, run_product  # noqa: E402
 
 
@@ -81,57 +81,6 @@ def case_hp(seed):
     return _c("morehp%d" % seed, op, r.choice([1, 2, 3]), C, O, size, k, stride=stride, padding=pad, dilation=dil,
               groups=groups, dgroups=dg, in_step=64, bias=r.random() < 0.5, tier="medium", seed=8000 + seed,
               offset_scale=r.choice([0.5, 1.0, 3.0]))
-
-
-def _wide_geometry(r, nd, kmax, hi):
-    """Per-axis kernel extents up to kmax (tap counts the case list and the other campaigns never reach: K = 16 ... 49 in 2-D,
-    up to 125 in 3-D), strides and dilations up to 3, paddings up to 'same' + 1, input extents from the smallest that still gives
-    one output position."""
-    k = tuple(r.choice([1, 2, 3, 4, 5, kmax]) for _ in range(nd))
-    if r.random() < 0.5:
-        k = (max(k),) * nd
-    stride = tuple(r.choice([1, 1, 2, 3]) for _ in range(nd))
-    dil = tuple(r.choice([1, 1, 2, 3]) for _ in range(nd))
-    pad = tuple(r.choice([0, 1, d_ * (k_ - 1) // 2, d_ * (k_ - 1) // 2 + 1]) for k_, d_ in zip(k, dil))
-    size = tuple(r.randint(max(1, d_ * (k_ - 1) + 1 - 2 * p_), max(hi, d_ * (k_ - 1) + 2))
-                 for k_, d_, p_ in zip(k, dil, pad))
-    return k, stride, dil, pad, size
-
-
-def case_f32_wide(seed):
-    r = random.Random(99000 + seed)
-    nd = r.choice([2, 2, 3])
-    modulated = r.random() < 0.6
-    op = {(2, False): D2, (2, True): M2, (3, False): D3, (3, True): M3}[(nd, modulated)]
-    k, stride, dil, pad, size = _wide_geometry(r, nd, 7 if nd == 2 else 5, 22 if nd == 2 else 8)
-    groups = r.choice([1, 1, 2])
-    dg = r.choice([1, 1, 2, 4])
-    C = dg * groups * r.choice([8, 16, 32]) if dg * groups > 1 else r.choice([16, 24, 32, 64, 128])
-    O = r.choice([16, 17, 32, 48, 64, 128])
-    O = (O + groups - 1) // groups * groups
-    B = r.choice([1, 2, 3, 7, 17]) if nd == 2 else r.choice([1, 2, 5])
-    return _c("wide%d" % seed, op, B, C, O, size, k, stride=stride, padding=pad, dilation=dil, groups=groups, dgroups=dg,
-              in_step=r.choice([1, 64]), bias=r.random() < 0.5, tier="medium", seed=9000 + seed,
-              offset_scale=r.choice([0.5, 2.0, 8.0]))
-
-
-def case_hp_wide(seed):
-    r = random.Random(66000 + seed)
-    nd = r.choice([2, 2, 3])
-    modulated = r.random() < 0.6
-    op = {(2, False): D2, (2, True): M2, (3, False): D3, (3, True): M3}[(nd, modulated)]
-    k, stride, dil, pad, size = _wide_geometry(r, nd, 7 if nd == 2 else 4, 16 if nd == 2 else 6)
-    size = size[:-1] + (max(size[-1], 2),)
-    groups = r.choice([1, 1, 2, 4])
-    dg = r.choice([1, 1, 2, 4])
-    C = r.choice([32, 64, 128])
-    while C % groups or C % dg:
-        C *= 2
-    O = r.choice([8, 32, 48, 64, 128])
-    O = (O + groups - 1) // groups * groups
-    return _c("widehp%d" % seed, op, r.choice([1, 2, 3]), C, O, size, k, stride=stride, padding=pad, dilation=dil,
-              groups=groups, dgroups=dg, in_step=64, bias=r.random() < 0.5, tier="medium", seed=6000 + seed,
-              offset_scale=r.choice([0.5, 2.0, 8.0]))
 
 
 GUARD = 1 << 16
