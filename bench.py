@@ -29,6 +29,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this host needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails with the legacy mode); the GPU box
+# exports it already -- kept here so that a bare `python bench.py --gpus N` from a clean environment works too
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
