@@ -204,15 +204,21 @@ __global__ __launch_bounds__(256, 2) void hp_fwd_kernel(
 
   // ---- epilogue: + bias, store [B, O, S_o]; lanes 0-31 -> 32 consecutive pixels ----
   if (live) {
+    if (g.with_bias) {   // bias values first, as independent loads (hp_fwd2.hip)
+#pragma unroll
+      for (int ob = 0; ob < MB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = (orange * MB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          acc[ob][r] += T::ldf(bias + (o < g.O ? o : 0));
+        }
+    }
 #pragma unroll
     for (int ob = 0; ob < MB; ++ob)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = (orange * MB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (o < g.O) {
-          const float bv = g.with_bias ? T::ldf(bias + o) : 0.f;
-          T::stf(output + ((int64_t)b * g.O + o) * g.S_o + pix, acc[ob][r] + bv);
-        }
+        if (o < g.O) T::stf(output + ((int64_t)b * g.O + o) * g.S_o + pix, acc[ob][r]);
       }
   }
 }

@@ -406,15 +406,23 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
 
   // ---- epilogue: + bias, store [B, O, S_o]; lanes 0-31 -> 32 consecutive pixels ----
   if (live) {
+    // the lane's 16 MB bias values first, as independent loads (inside the store loop below each one sat between two dependent
+    // stores: +0.09 ms on the cfg5 forward with bias, profiles/r05_experiments.md 28)
+    if (g.with_bias) {
+#pragma unroll
+      for (int ob = 0; ob < MB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = (orange * MB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          acc[ob][r] += T::ldf(bias + (o < g.O ? o : 0));
+        }
+    }
 #pragma unroll
     for (int ob = 0; ob < MB; ++ob)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = (orange * MB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (o < g.O) {
-          const float bv = g.with_bias ? T::ldf(bias + o) : 0.f;
-          T::stf(output + ((int64_t)b * g.O + o) * g.S_o + pix, acc[ob][r] + bv);
-        }
+        if (o < g.O) T::stf(output + ((int64_t)b * g.O + o) * g.S_o + pix, acc[ob][r]);
       }
   }
 #ifdef F2_TIMING

@@ -251,24 +251,48 @@ __global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, in
   }
 }
 
-// grad_bias[o] (+)= sum over (b, pix) of grad_out[b][o][pix]; one workgroup per output channel
+// grad_bias[o] (+)= sum over (b, pix) of grad_out[b][o][pix].  One workgroup of 1024 threads per output channel; a row
+// [S_o] of (image, channel) is read with 16-byte loads (eight elements), four in flight per thread, the few elements before
+// the row's first / after its last 16-byte boundary one by one.  Per-thread fp32 partials and a fixed tree: bit-reproducible
+// from run to run.  (Until round 5: 256 threads reading one element each per step -- 2 bytes per lane and one load in flight:
+// +0.14 ms on the cfg3 backward, +0.88 ms on cfg5 with bias; profiles/r05_experiments.md 28.)
 template <typename T>
-__global__ __launch_bounds__(256) void hp_grad_bias_kernel(Geom g, const typename T::Raw *__restrict__ go,
-                                                           typename T::Raw *__restrict__ gb) {
-  __shared__ float red[256];
-  const int o = blockIdx.x;
-  float s = 0.f;
+__device__ __forceinline__ float sum8(const U4 &v) {
+  return ((T::lo(v.x) + T::hi(v.x)) + (T::lo(v.y) + T::hi(v.y))) + ((T::lo(v.z) + T::hi(v.z)) + (T::lo(v.w) + T::hi(v.w)));
+}
+constexpr int kBiasThreads = 1024;
+template <typename T>
+__global__ __launch_bounds__(kBiasThreads) void hp_grad_bias_kernel(Geom g, const typename T::Raw *__restrict__ go,
+                                                                    typename T::Raw *__restrict__ gb) {
+  __shared__ float red[kBiasThreads];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   for (int b = 0; b < g.B; ++b) {
     const typename T::Raw *src = go + ((int64_t)b * g.O + o) * g.S_o;
-    for (int i = threadIdx.x; i < g.S_o; i += 256) s += T::ldf(src + i);
+    int head = (int)((8 - (((uintptr_t)src >> 1) & 7)) & 7);   // elements before the first 16-byte boundary
+    if (head > g.S_o) head = g.S_o;
+    const int nvec = (g.S_o - head) >> 3;
+    const int tail0 = head + nvec * 8;
+    if (tid < head) s2 += T::ldf(src + tid);
+    if (tid < g.S_o - tail0) s3 += T::ldf(src + tail0 + tid);
+    const U4 *v = reinterpret_cast<const U4 *>(src + head);
+    int i = tid;
+    for (; i + 3 * kBiasThreads < nvec; i += 4 * kBiasThreads) {
+      const U4 a0 = v[i], a1 = v[i + kBiasThreads], a2 = v[i + 2 * kBiasThreads], a3 = v[i + 3 * kBiasThreads];
+      s0 += sum8<T>(a0);
+      s1 += sum8<T>(a1);
+      s2 += sum8<T>(a2);
+      s3 += sum8<T>(a3);
+    }
+    for (; i < nvec; i += kBiasThreads) s0 += sum8<T>(v[i]);
   }
-  red[threadIdx.x] = s;
+  red[tid] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) {
-    if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+  for (int d = kBiasThreads / 2; d > 0; d >>= 1) {
+    if (tid < d) red[tid] += red[tid + d];
     __syncthreads();
   }
-  if (threadIdx.x == 0) T::stf(gb + o, g.acc_w ? T::ldf(gb + o) + red[0] : red[0]);
+  if (tid == 0) T::stf(gb + o, g.acc_w ? T::ldf(gb + o) + red[0] : red[0]);
 }
 
 }  // namespace
@@ -319,10 +343,10 @@ int hp_reduce_grad_weight(const Geom &g, const HpDims &hd, int ranges, int dtype
 int hp_grad_bias(const Geom &g, int dtype, const void *grad_output, void *grad_bias,
                  hipStream_t stream) {
   if (dtype == MDCONV_F16)
-    hipLaunchKernelGGL((hp_grad_bias_kernel<F16>), dim3(g.O), dim3(256), 0, stream, g,
+    hipLaunchKernelGGL((hp_grad_bias_kernel<F16>), dim3(g.O), dim3(kBiasThreads), 0, stream, g,
                        (const _Float16 *)grad_output, (_Float16 *)grad_bias);
   else
-    hipLaunchKernelGGL((hp_grad_bias_kernel<BF16>), dim3(g.O), dim3(256), 0, stream, g,
+    hipLaunchKernelGGL((hp_grad_bias_kernel<BF16>), dim3(g.O), dim3(kBiasThreads), 0, stream, g,
                        (const __bf16 *)grad_output, (__bf16 *)grad_bias);
   return check_launch("hp_grad_bias");
 }
