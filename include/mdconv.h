@@ -23,7 +23,7 @@
  *    caller-allocated entry points do (deformable_conv.cu:327-333; the Python wrapper zero-fills,
  *    modulated_deform_conv.py:53-56).  For the modulated-2D op, whose reference entry point
  *    allocates zeros itself (mdeformable_conv.cu:404-411), the binding passes uninitialised
- *    buffers and switches the call to overwrite mode (mdconv_set_accumulate).
+ *    buffers and asks for overwrite mode in the descriptor (`accumulate = 0`, ABI v2).
  *  - `in_step` is accepted for signature parity (reference README.md:30-31) and validated
  *    (> 0); results never depend on it (the reference's own modulated-2D op is in_step-invariant).
  *  - Return value: 0 on success, a negative MDCONV_E* code otherwise; mdconv_last_error() gives
@@ -39,7 +39,14 @@
 extern "C" {
 #endif
 
-#define MDCONV_ABI_VERSION 1
+/* ABI history.  v1: the eight entry points, call modes as thread-local / process-wide setters
+ * (mdconv_set_accumulate, mdconv_set_input_layout, mdconv_set_path).  v2 (this header): the call
+ * modes travel IN THE DESCRIPTOR (`accumulate`, `input_layout`, `path`), so a C caller has no hidden
+ * state between its calls.  Binary compatibility: a v2 caller ORs MDCONV_DESC_V2 into `ndim`; the
+ * library reads the v2 tail of the struct only then.  A descriptor without the tag (a caller built
+ * against the v1 header, whose struct ends at `with_bias`) keeps v1 behaviour: the setters apply. */
+#define MDCONV_ABI_VERSION 2
+#define MDCONV_DESC_V2 0x100   /* flag in mdconv_desc.ndim: the descriptor carries the v2 fields */
 
 /* AT_DISPATCH_FLOATING_TYPES_AND_HALF (mdeformable_conv.cu:101) + bfloat16 */
 enum { MDCONV_F32 = 0, MDCONV_F16 = 1, MDCONV_F64 = 2, MDCONV_BF16 = 3 };
@@ -58,7 +65,7 @@ enum {
 enum { MDCONV_PATH_AUTO = 0, MDCONV_PATH_DIRECT = 1, MDCONV_PATH_MFMA = 2 };
 
 typedef struct mdconv_desc {
-  int ndim;       /* 2 or 3 */
+  int ndim;       /* 2 or 3, | MDCONV_DESC_V2 when the v2 fields below are filled in */
   int modulated;  /* 0 = DeformConv (DCNv1), 1 = ModulatedDeformConv (DCNv2) */
   int dtype;      /* MDCONV_F32 / F16 / F64 / BF16 -- element type of every tensor */
   int batch;      /* B */
@@ -73,7 +80,19 @@ typedef struct mdconv_desc {
   int dgroups;    /* `deformable_group` */
   int in_step;    /* accepted, validated > 0, otherwise unused */
   int with_bias;
+  /* ---- ABI v2: read only when ndim carries MDCONV_DESC_V2 (use MDCONV_DESC_INIT) ---- */
+  int accumulate;   /* backward write mode: 1 = ACCUMULATE into grad_* (the reference's caller-allocated
+                       entry points), 0 = OVERWRITE grad_* (buffers need not be initialised) */
+  int input_layout; /* MDCONV_LAYOUT_NCHW or MDCONV_LAYOUT_CHANNELS_LAST (see below) */
+  int path;         /* MDCONV_PATH_AUTO = the process default (MDCONV_PATH / mdconv_set_path), or a forced
+                       MDCONV_PATH_DIRECT / MDCONV_PATH_MFMA for this call */
+  int reserved[5];  /* must be 0 */
 } mdconv_desc;
+
+/* Initialiser of a v2 descriptor: `mdconv_desc d = MDCONV_DESC_INIT(2);` then fill in the shape.
+ * (reference semantics by default: accumulate, NCHW input, process-default path) */
+#define MDCONV_DESC_INIT(nd) { (nd) | MDCONV_DESC_V2, 0, 0, 0, 0, 0, {0, 0, 1}, {0, 0, 1}, {1, 1, 1}, \
+                               {0, 0, 0}, {1, 1, 1}, 1, 1, 64, 0, 1, 0, 0, {0, 0, 0, 0, 0} }
 
 int mdconv_abi_version(void);
 const char *mdconv_last_error(void);
@@ -84,8 +103,9 @@ int mdconv_out_size(const mdconv_desc *d, int axis);
 /* Scratch bytes needed by the forward (backward = 0) or backward (backward = 1) of `d`. */
 size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward);
 
-/* Force a kernel path for subsequent calls of this process (MDCONV_PATH_*); returns the
- * previous value.  The environment variable MDCONV_PATH=auto|direct|mfma sets the default. */
+/* Process-wide default kernel path (MDCONV_PATH_*) for descriptors that do not name one; returns the
+ * previous value.  The environment variable MDCONV_PATH=auto|direct|mfma sets the initial default.
+ * Per call: mdconv_desc.path (ABI v2). */
 int mdconv_set_path(int path);
 /* Path the last forward / backward call of this thread actually ran (MDCONV_PATH_DIRECT/MFMA). */
 int mdconv_last_path(void);
@@ -106,18 +126,19 @@ int mdconv_profile_read(int which, double *total_ms);
 const char *mdconv_profile_name(int which);
 void mdconv_profile_reset(void);
 
-/* Backward write mode of the calling thread: 1 (default) = ACCUMULATE into grad_* like the
- * reference's caller-allocated entry points; 0 = OVERWRITE grad_* (buffers need not be
- * initialised: saves the caller's zero-fills and the read half of every read-modify-write).
- * Returns the previous mode. */
+/* ABI v1 setter, kept for callers built against the v1 header: backward write mode of the calling
+ * thread for descriptors WITHOUT MDCONV_DESC_V2 (1 = accumulate, the default; 0 = overwrite).  Returns
+ * the previous mode.  v2 descriptors carry `accumulate` themselves and ignore it. */
 int mdconv_set_accumulate(int on);
 
-/* Memory format of `input` for the calling thread's next calls:
+/* Memory format of `input`, mdconv_desc.input_layout:
  * MDCONV_LAYOUT_NCHW (default, the reference's [B, C, spatial...]) or MDCONV_LAYOUT_CHANNELS_LAST
  * ([B, spatial..., C], torch.channels_last / channels_last_3d).  Channels-last input is what the
  * native 16-bit kernels gather from, so it saves their layout pass; it is accepted for fp16 / bf16
  * tensors with C_in a multiple of 32 only (MDCONV_EUNSUPPORTED otherwise).  Every other tensor,
- * grad_input included, keeps the reference layout.  Returns the previous setting. */
+ * grad_input included, keeps the reference layout.
+ * mdconv_set_input_layout() is the ABI v1 setter (calling thread, descriptors without MDCONV_DESC_V2);
+ * it returns the previous setting. */
 enum { MDCONV_LAYOUT_NCHW = 0, MDCONV_LAYOUT_CHANNELS_LAST = 1 };
 int mdconv_set_input_layout(int layout);
 /* 1 if the forward (backward = 0) / backward (backward = 1) of `d` accepts `input` in `layout`,

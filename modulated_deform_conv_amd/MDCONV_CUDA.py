@@ -59,7 +59,8 @@ def _desc(nd, modulated, input, weight, ksz, stride, pad, dil, group, deformable
         raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)."
                            % (input.shape[1], weight.shape[1] * group))
     d = _capi.MdconvDesc()
-    d.ndim, d.modulated, d.dtype = nd, int(modulated), _DTYPES[input.dtype]
+    d.ndim, d.modulated, d.dtype = nd | _capi.DESC_V2, int(modulated), _DTYPES[input.dtype]
+    d.accumulate, d.input_layout, d.path = _capi.accumulate_mode(), 0, _capi.PATH_AUTO
     d.batch, d.c_in, d.c_out = input.shape[0], input.shape[1], weight.shape[0]
     fill = lambda v, f: tuple(int(x) for x in v) + (f,) * (3 - nd)
     d.in_sz = (ctypes.c_int * 3)(*fill(input.shape[2:], 1))
@@ -112,8 +113,8 @@ def _same(ref, **tensors):
 
 def _run(fn_name, d, backward, args_before_ws, input):
     L = _capi.lib()
-    cl = not input.is_contiguous() and _is_channels_last(input)
-    with torch.cuda.device(input.device), _capi.channels_last_input(cl):
+    d.input_layout = int(not input.is_contiguous() and _is_channels_last(input))
+    with torch.cuda.device(input.device):
         ws_bytes = L.mdconv_workspace_bytes(ctypes.byref(d), int(backward))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device) if ws_bytes else None
         stream = torch.cuda.current_stream().cuda_stream
@@ -227,7 +228,7 @@ def modulated_deform_conv2d_backward_cuda(input, weight, bias, offset, mask, gra
     _check_side(d, 2, kernel_h * kernel_w, offset, mask, grad_output, "grad_output", osz)
     # the reference allocates zeros here (mdeformable_conv.cu:404-411) and adds into them; this
     # entry point owns its results, so it allocates uninitialised memory and asks the library to
-    # WRITE the gradients (no zero fills, no read-modify-write)
+    # WRITE the gradients (mdconv_desc.accumulate = 0: no zero fills, no read-modify-write)
     grad_input = torch.empty_like(input, memory_format=torch.contiguous_format)
     grad_offset = torch.empty_like(offset)
     grad_mask = torch.empty_like(mask)
@@ -235,11 +236,11 @@ def modulated_deform_conv2d_backward_cuda(input, weight, bias, offset, mask, gra
     grad_bias = torch.empty_like(bias)
     _backward_checks(input, weight, offset, mask, grad_input, grad_weight, grad_bias, grad_offset,
                      grad_mask, grad_output, d, with_bias)
-    with _capi.overwrite_grads():
-        _run("mdconv_modulated_deform_conv2d_backward", d, True,
-             [_ptr(input), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(mask), _ptr(grad_output),
-              _ptr(grad_input), _ptr(grad_offset), _ptr(grad_mask), _ptr(grad_weight),
-              _ptr(grad_bias)], input)
+    d.accumulate = 0
+    _run("mdconv_modulated_deform_conv2d_backward", d, True,
+         [_ptr(input), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(mask), _ptr(grad_output),
+          _ptr(grad_input), _ptr(grad_offset), _ptr(grad_mask), _ptr(grad_weight),
+          _ptr(grad_bias)], input)
     return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias)
 
 

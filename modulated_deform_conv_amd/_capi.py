@@ -5,12 +5,15 @@ raises, loudly.
 """
 import ctypes
 import os
+import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDCONV_LIB") or os.path.join(HERE, "libmdconv_hip.so")
 
 F32, F16, F64, BF16 = 0, 1, 2, 3
 PATH_AUTO, PATH_DIRECT, PATH_MFMA = 0, 1, 2
+ABI_VERSION = 2
+DESC_V2 = 0x100   # MDCONV_DESC_V2: the descriptor carries accumulate / input_layout / path
 
 EXPORTS = (
     "mdconv_abi_version", "mdconv_last_error", "mdconv_out_size", "mdconv_workspace_bytes",
@@ -26,13 +29,15 @@ EXPORTS = (
 
 
 class MdconvDesc(ctypes.Structure):
-    """Mirror of ``struct mdconv_desc`` (include/mdconv.h)."""
+    """Mirror of ``struct mdconv_desc`` (include/mdconv.h, ABI v2: the call modes travel in the descriptor)."""
     _fields_ = [("ndim", ctypes.c_int), ("modulated", ctypes.c_int), ("dtype", ctypes.c_int),
                 ("batch", ctypes.c_int), ("c_in", ctypes.c_int), ("c_out", ctypes.c_int),
                 ("in_sz", ctypes.c_int * 3), ("k_sz", ctypes.c_int * 3),
                 ("stride", ctypes.c_int * 3), ("pad", ctypes.c_int * 3), ("dil", ctypes.c_int * 3),
                 ("groups", ctypes.c_int), ("dgroups", ctypes.c_int), ("in_step", ctypes.c_int),
-                ("with_bias", ctypes.c_int)]
+                ("with_bias", ctypes.c_int),
+                ("accumulate", ctypes.c_int), ("input_layout", ctypes.c_int), ("path", ctypes.c_int),
+                ("reserved", ctypes.c_int * 5)]
 
 
 _lib = None
@@ -71,7 +76,7 @@ def lib():
         L.mdconv_input_layout_supported.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         for name in EXPORTS[11:]:
             getattr(L, name).restype = ctypes.c_int
-        if L.mdconv_abi_version() != 1:
+        if L.mdconv_abi_version() != ABI_VERSION:
             raise ImportError("libmdconv_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -100,30 +105,25 @@ def last_kernels():
 PROFILE_SLOTS = 5   # forward GEMM, backward data GEMM, backward weight GEMM, grad_input gather
 
 
+_modes = threading.local()   # Python-side default of mdconv_desc.accumulate for descriptors built in this thread
+
+
+def accumulate_mode():
+    """Value for ``mdconv_desc.accumulate`` of a descriptor built now (1 unless inside ``overwrite_grads``)."""
+    return getattr(_modes, "accumulate", 1)
+
+
 class overwrite_grads:
-    """Context manager: backward entry points called inside WRITE their gradients instead of adding
-    to them (include/mdconv.h: mdconv_set_accumulate), so the buffers may be torch.empty."""
+    """Context manager: backward entry points of MDCONV_CUDA called inside WRITE their gradients instead of
+    adding to them (``mdconv_desc.accumulate = 0``, include/mdconv.h), so the buffers may be torch.empty.
+    The mode travels in each call's descriptor; no library state is touched."""
 
     def __enter__(self):
-        self._prev = lib().mdconv_set_accumulate(0)
+        self._prev = accumulate_mode()
+        _modes.accumulate = 0
 
     def __exit__(self, *exc):
-        lib().mdconv_set_accumulate(self._prev)
-        return False
-
-
-class channels_last_input:
-    """Context manager: `input` of the entry points called inside is channels-last
-    (include/mdconv.h: mdconv_set_input_layout)."""
-
-    def __init__(self, on=True):
-        self._on = on
-
-    def __enter__(self):
-        self._prev = lib().mdconv_set_input_layout(1 if self._on else 0)
-
-    def __exit__(self, *exc):
-        lib().mdconv_set_input_layout(self._prev)
+        _modes.accumulate = self._prev
         return False
 
 

@@ -30,13 +30,6 @@ namespace mdconv {
 namespace {
 
 
-#ifdef HP_TIMING
-// developer instrumentation (tools/hp_timing.py): cycles per phase, summed over waves 0 and 1
-__device__ unsigned long long g_hp_timing[16];
-#define HP_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define HP_T(slot) do { } while (0)
-#endif
 
 // advance (b, oc[]) -- image index and output coordinates of a pixel -- by `adv` flattened pixels
 template <int ND> __device__ __forceinline__ void advance_pixel(const Geom &g, int adv, int &b, int *oc) {
@@ -95,9 +88,6 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
   const int n_first = t_lo * 32;
   const int b_first = n_first / g.S_o, p_first = n_first - b_first * g.S_o;
 
-#ifdef HP_TIMING
-  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
-#endif
 
   if (is_state) {
     // =====================================================================================
@@ -351,7 +341,6 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
 
   for (int tile = t_lo; tile < t_hi; ++tile) {
     const int buf = (tile - t_lo) & 1;
-    HP_T(7);
     // ================= P2: GEMM-1 -> Gc =================
     if (active) {
       f32x16 gc;
@@ -373,9 +362,7 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
       *reinterpret_cast<U4 *>(dst) = pack8<T>(g0);
       *reinterpret_cast<U4 *>(dst + 8) = pack8<T>(g1);
     }
-    HP_T(0);
     __syncthreads();   // B2
-    HP_T(1);
     // ================= P3: gather role =================
     {
       // 2-D: both items' gathers are requested up front; 3-D (8 corners): one item at a time
@@ -437,15 +424,11 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
       if (NI == 2) request(1, NI - 1);
       // the next tile's grad_out goes to the other LDS buffer while the gathers are in flight
       if (tile + 1 < t_hi) g_store(buf ^ 1);
-      HP_T(2);
       consume(0, 0);
-      HP_T(3);
       if (NI == 1) request(1, 0);
       consume(1, NI - 1);
     }
-    HP_T(4);
     __syncthreads();   // B3
-    HP_T(5);
     // ================= P4: GEMM-2 =================
     if (tile + 2 < t_hi) { g_load(); g_advance(); }
     if (active) {
@@ -462,14 +445,9 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
         }
       }
     }
-    HP_T(6);
     cpx += 32;
     while (cpx >= g.S_o) { cpx -= g.S_o; ++cb; }
   }
-#ifdef HP_TIMING
-  if (lane == 0 && wave < 2)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_hp_timing[wave * 8 + i], t_acc[i]);
-#endif
   if (active) {
     float4 *dst = reinterpret_cast<float4 *>(
         part + ((((int64_t)tap * hd.ranges + range) * hd.cblks + cblk) * MB2) * 1024 + lane * 16);
@@ -483,15 +461,6 @@ __global__ __launch_bounds__(64 * (WAVES + NS), WAVES >= 8 ? 1 : 2) void hp_bwd2
 
 }  // namespace
 
-#ifdef HP_TIMING
-extern "C" void mdconv_debug_timing(unsigned long long *out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hp_timing), sizeof(g_hp_timing));
-  if (reset) {
-    unsigned long long z[16] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hp_timing), z, sizeof(z));
-  }
-}
-#endif
 
 size_t hp_bwd2_lds_bytes(const Geom &g, const HpDims &hd) {
   const int nc = 1 << g.nd;

@@ -36,13 +36,6 @@
 namespace mdconv {
 
 namespace {
-#ifdef B3_TIMING
-// developer instrumentation (tools/b1_timing.py --bwd3): cycles per phase of the tap loop, summed over all waves
-__device__ unsigned long long g_b3_timing[8];
-#define B3_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define B3_T(slot) do { } while (0)
-#endif
 
 
 constexpr int kChunkRows = 64;   // grad_out rows staged through LDS at a time (4 k-steps)
@@ -50,10 +43,7 @@ constexpr int kChunkRows = 64;   // grad_out rows staged through LDS at a time (
 // 32-63 build (t + 1, pixel) -- before, both half-waves computed the same state and one discarded it.  The state
 // table has one row set per wave, so lanes 32-63 keep their row in registers (18 dwords) until tap t + 1 starts;
 // the per-axis factors `fac` stay in the half-wave that built them, which is also the one that finishes the tap's
-// grad_offset / grad_mask.  B3_PAIR=0 restores one build per tap (A/B switch).
-#ifndef B3_PAIR
-#define B3_PAIR 1
-#endif
+// grad_offset / grad_mask.
 
 template <int ND, bool MOD, typename T, int LPP, int NKS>
 __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
@@ -104,9 +94,6 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
   const rsrc_t r_col = make_rsrc(colbuf + (size_t)b0 * gcol_img, gcol_img * 2);
   const int S_e = hp_anchor_space(g);
 
-#ifdef B3_TIMING
-  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
-#endif
   // ---- W^T slab of tap 0 -> LDS (whole workgroup) ----
   for (int i = tid; i < WTOT; i += 256) Ws[i] = wpb[i];
 
@@ -151,7 +138,6 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
   Raw dlr[ND], mlr;
   const Raw *off_px = offset + (int64_t)b * (ND * g.K) * g.S_o + pix;
   const Raw *msk_px = MOD ? mask + (int64_t)b * g.K * g.S_o + pix : nullptr;
-#if B3_PAIR
   // the tap THIS lane builds next (lanes 32-63 one ahead), its coordinates kept incrementally
   int b_tap = kh, b_tcd[ND];
   {
@@ -180,15 +166,8 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     for (int a = 0; a < ND; ++a) dlr[a] = off_px[((int64_t)tp * ND + a) * g.S_o];
     if (MOD) mlr = msk_px[(int64_t)tp * g.S_o];
   };
-#else
-  auto fetch = [&](int tap) {
-#pragma unroll
-    for (int a = 0; a < ND; ++a) dlr[a] = off_px[((int64_t)tap * ND + a) * g.S_o];
-    if (MOD) mlr = msk_px[(int64_t)tap * g.S_o];
-  };
-#endif
   struct Fac { float wl[ND], wh[ND], sl[ND], sh[ND], mg; } fac;
-  int held[SW];   // B3_PAIR: the state row lanes 32-63 built for the odd tap, until that tap starts
+  int held[SW];   // the state row lanes 32-63 built for the odd tap, until that tap starts
 #pragma unroll
   for (int q = 0; q < SW; ++q) held[q] = 0;
   auto store_row = [&](const int (&ev)[SW]) {
@@ -235,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     }
   };
   auto finish = [&](int tap) {   // grad_offset / grad_mask of (tap, this lane's pixel) from the reduced S in its state row
-    if ((B3_PAIR ? kh == (tap & 1) : lane < 32) && live) {
+    if (kh == (tap & 1) && live) {
       float S[NC];
       const int *sp = St + pl * SW;
 #pragma unroll
@@ -291,11 +270,7 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     }
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) {
-#ifdef ABL_NOGATHER   // developer ablation (timing only): every corner from one cache-resident row
-      s.x[ci] = buf_load4u(r_xt, (ev[ci] & 0xff00) + oc8 * 16, 0);
-#else
       s.x[ci] = buf_load4u(r_xt, ev[ci] + oc8 * 16, 0);
-#endif
     }
   };
   auto consume = [&](const Set &s, int it) {
@@ -328,24 +303,9 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
       }
       cq = pack8<T>(col);
     }
-#ifdef ABL_NOSTORE   // developer ablation (timing only): rows are (practically) never written
-    if (cq.x != 0x12345678u || gq.y != 0x9abcdef0u) {
-    } else
-#endif
     if (one_img) {   // scalar row base, dead pixels out of range (dropped)
-#if defined(ABL_STORE_L2)    // developer ablation (timing only): both rows stored, into a 1 MB region that never leaves the L2
-      buf_store4u_nt(r_gcol, (tail.x & 0xfff00) + oc8 * 16, 0, gq);
-      buf_store4u_nt(r_col, (tail.x & 0xfff00) + oc8 * 16, 0, cq);
-#elif defined(ABL_STORE_GQ_ONLY)   // ... only the grad_col rows / only the column rows
-      buf_store4u_nt(r_gcol, tail.x + oc8 * 16, 0, gq);
-      if (cq.x == 0x12345678u && gq.y == 0x9abcdef0u) buf_store4u_nt(r_col, tail.x + oc8 * 16, 0, cq);
-#elif defined(ABL_STORE_CQ_ONLY)
-      buf_store4u_nt(r_col, tail.x + oc8 * 16, 0, cq);
-      if (cq.x == 0x12345678u && gq.y == 0x9abcdef0u) buf_store4u_nt(r_gcol, tail.x + oc8 * 16, 0, gq);
-#else
       buf_store4u_nt(r_gcol, tail.x + oc8 * 16, 0, gq);
       buf_store4u_nt(r_col, tail.x + oc8 * 16, 0, cq);
-#endif
     } else if (tail.x != kHpOob) {
       const size_t e = (size_t)tail.y * gcol_img + (tail.x >> 1) + oc8 * 8;
       *reinterpret_cast<U4 *>(gcol + e) = gq;
@@ -365,16 +325,10 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
     }
   };
 
-#if B3_PAIR
   fetch();
-#else
-  fetch(0);
-#endif
   __syncthreads();   // W^T slab of tap 0 is in LDS (and every wave is past its grad_out staging)
-  B3_T(6);   // prologue: W^T slab of tap 0, grad_out fragments
   for (int tap = 0; tap < g.K; ++tap) {
     if (wave_live) {
-#if B3_PAIR
       if ((tap & 1) == 0) {
         build_state(b_tap, b_tcd, b_tap < g.K, kh != 0);
         advance2();
@@ -382,15 +336,6 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
       } else if (kh) {
         store_row(held);
       }
-#else
-      {
-        int tcd[ND];
-        tap_coords<ND>(g, tap, tcd);
-        build_state(tap, tcd, lane < 32, false);
-      }
-      if (tap + 1 < g.K) fetch(tap + 1);
-#endif
-      B3_T(0);   // sampling state + next offsets
       // ---- matrix phase: GEMM-1 per 32-channel block -> Gc ----
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
@@ -407,9 +352,7 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
         *reinterpret_cast<U4 *>(dst + 8) = pack8<T>(g1);
       }
     }
-    B3_T(1);   // matrix phase -> Gc
     __syncthreads();   // B1: every wave is done with this tap's W^T slab
-    B3_T(2);   // barrier B1
     // ---- gather phase (+ the next tap's W^T slab, WPI pieces per iteration) ----
     // piece k of iteration `it`: element tid + (it * WPI + k) * 256 of the slab, loaded at the top of the
     // iteration (unconditionally, from a clamped index: a conditional load into a struct ended up in scratch)
@@ -440,31 +383,13 @@ __global__ __launch_bounds__(256, 2) void hp_bwd3_kernel(
       if (on0) wdst[i0] = w0;
       if (on1) wdst[i1] = w1;
     }
-    B3_T(3);   // gather phase (+ W^T staging)
     if (wave_live) finish(tap);
-    B3_T(4);   // grad_offset / grad_mask
     __syncthreads();   // B2: the next tap's W^T slab is complete
-    B3_T(5);   // barrier B2
   }
-#ifdef B3_TIMING
-  if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_b3_timing[i], t_acc[i]);
-#endif
 }
 
 }  // namespace
 
-#ifdef B3_TIMING
-}  // namespace mdconv
-extern "C" void mdconv_debug_timing_b3(unsigned long long *out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdconv::g_b3_timing), sizeof(mdconv::g_b3_timing));
-  if (reset) {
-    unsigned long long z[8] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(mdconv::g_b3_timing), z, sizeof(z));
-  }
-}
-namespace mdconv {
-#endif
 
 size_t hp_bwd3_lds_bytes(const HpDims &hd) {
   const size_t region = (size_t)32 * (hd.Cp + 8) * 2 > (size_t)kChunkRows * kPP * 2 ? (size_t)32 * (hd.Cp + 8) * 2

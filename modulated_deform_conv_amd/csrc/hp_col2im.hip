@@ -230,9 +230,6 @@ __global__ __launch_bounds__(256) void hp_col2im_kernel(Geom g, HpDims hd, int S
 // and writes them as 16-bit rows A[segment][anchor][s][channels].  Pass 2 is a 2^(ND-1)-point stencil
 // over A (target t takes s from anchor row t + s) plus the transpose to [B, C, S_i].
 // ---------------------------------------------------------------------------------------------
-#ifndef HP_C2I_UB
-#define HP_C2I_UB 4
-#endif
 constexpr int kRunA = 16;   // anchors per run: the carry-in anchor is read twice (1 / 16 of the rows)
 
 // Storage of the partial sums: the tensors' own 16-bit type for fp16 (11 significant bits; two to four of them are
@@ -251,7 +248,7 @@ __global__ __launch_bounds__(256) void hp_col2im_sums_kernel(Geom g, HpDims hd, 
   constexpr bool WIDE = sizeof(Sum) == 4;
   constexpr int L = ND - 1, NS = 1 << L;
   constexpr int NQ = 64 / LPD, RUNS = 4 * NQ;
-  constexpr int UB = HP_C2I_UB;            // rows per load group; two groups are in flight
+  constexpr int UB = 4;            // rows per load group; two groups are in flight
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane / LPD, r = lane % LPD;
   const int cseg = g.DG == 1 ? hd.Cp : g.Cdg;   // channels that share one list

@@ -118,16 +118,13 @@ __device__ __forceinline__ void buf_store4u(rsrc_t r, int voff, int soff, const 
 }
 
 // streaming variants for rows that are written once / read once (aux bit 1 = nt): keeps them from evicting
-// the gathered input rows from the L2.  HP_NT = 0 builds them as plain accesses (A/B switch).
-#ifndef HP_NT
-#define HP_NT 1
-#endif
+// the gathered input rows from the L2.
 __device__ __forceinline__ U4 buf_load4u_nt(rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, HP_NT ? 2 : 0));
+  return __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2));
 }
 __device__ __forceinline__ void buf_store4u_nt(rsrc_t r, int voff, int soff, const U4 &v) {
   typedef unsigned int u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, HP_NT ? 2 : 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 2);
 }
 
 // acc[j] += w * element j of the 8 packed values in v

@@ -19,13 +19,6 @@
 namespace mdconv {
 
 namespace {
-#ifdef F2_TIMING
-// developer instrumentation (tools/b1_timing.py --fwd2): cycles per phase of the stage loop, summed over all waves
-__device__ unsigned long long g_f2_timing[8];
-#define F2_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define F2_T(slot) do { } while (0)
-#endif
 
 
 constexpr int kStage = 4;    // 16-channel chunks per K stage (= 64 channels = one 128-byte line)
@@ -33,11 +26,7 @@ constexpr int kStage = 4;    // 16-channel chunks per K stage (= 64 channels = o
 // (the next tap, or the next deformable group of the tap), instead of both half-waves computing the same state and
 // one of them discarding it.  The table has three slots per wave (state s lives in slot s % 3): when the pair
 // (s + 2, s + 3) is built, during the last stage of state s + 1, the slots of s + 2 and of s (done) are free.
-// F2_PAIR=0 restores one state per build and two slots (A/B switch).
-#ifndef F2_PAIR
-#define F2_PAIR 1
-#endif
-constexpr int kStSlots = F2_PAIR ? 3 : 2;
+constexpr int kStSlots = 3;
 constexpr int kBtP = 72;     // LDS pitch (16-bit elements) of a pixel row of the B tile: 64 + 8
 
 // GRP = false: one conv group -- every chunk feeds every output-channel block, no table lookups.
@@ -55,15 +44,6 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
   U4 *As = reinterpret_cast<U4 *>(smem);                                   // [2][kStage][nmax][64]
   Raw *Bt_all = reinterpret_cast<Raw *>(As + 2 * kStage * nmax * 64);      // [4][32][kBtP]
   int *St_all = reinterpret_cast<int *>(Bt_all + 4 * 32 * kBtP);           // [4][kStSlots][32][SW]
-#ifdef ABL_FWD_WINDOW
-  // Developer ablation (TIMING ONLY, results are wrong): what an LDS-staged input window could buy at best.  The
-  // workgroup first copies kWinFill rows of 128 bytes (a 128-pixel tile + a 4-pixel halo of one 64-channel group =
-  // 17 x 25 rows) from xt into a 32 KB LDS region (wrapping: two workgroups per CU must still fit) and then serves
-  // EVERY corner read from that region at (row index & 255) -- no window coordinates, no in-window test, no fallback
-  // path for samples outside the halo: an upper bound on the speed of such a kernel.
-  constexpr int kWinRows = 256, kWinFill = 425;
-  unsigned char *Win = reinterpret_cast<unsigned char *>(St_all + 4 * kStSlots * 32 * SW);
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,7 +116,6 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
 #pragma unroll
     for (int q = 0; q < SW; q += 4) *reinterpret_cast<int4 *>(sp + q) = make_int4(ev[q], ev[q + 1], ev[q + 2], ev[q + 3]);
   };
-#if F2_PAIR
   // states of a tap: one per run of `spd` stages (deformable group); state index = tap * ndg + run
   const int ndg = g.DG == 1 ? 1 : (nst + spd - 1) / spd;
   const int nstates = g.K * ndg;
@@ -180,25 +159,6 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     advance();
     advance();
   };
-#else
-  auto fetch = [&](int tap, int dg) {
-    const Raw *op = off_px + (int64_t)(dg * g.K + tap) * ND * g.S_o;
-#pragma unroll
-    for (int a = 0; a < ND; ++a) dlr[a] = op[(int64_t)a * g.S_o];
-    if (MOD) mlr = msk_px[(int64_t)(dg * g.K + tap) * g.S_o];
-  };
-  auto build = [&](int tap, int slot) {   // from the fetched offsets / mask
-    float dl[ND], ml = 1.f;
-#pragma unroll
-    for (int a = 0; a < ND; ++a) dl[a] = T::ldf(&dlr[a]);
-    if (MOD) ml = T::ldf(&mlr);
-    int tcd[ND];
-    tap_coords<ND>(g, tap, tcd);
-    TapCoef<ND, float> tc;
-    make_tap<ND, float>(g, oc, tcd, dl, false, tc);
-    if (lane < 32) store_state(tc, ml, slot);
-  };
-#endif
 
   // ---- weight staging: fragment f of a stage = (chunk f / MB, block f % MB); wave w moves
   // fragments w, w + 4, ...; with groups only the blocks a chunk can reach, compacted ----
@@ -254,15 +214,7 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     }
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) {
-#ifdef ABL_FWD_NOGATHER   // developer ablation (timing only): every corner from one cache-resident row
-      s.v[ci] = buf_load4u(r_xt, (ev[ci] & 0xff00) + lane_off, cbase2);
-#else
-#ifdef ABL_FWD_WINDOW
-      s.v[ci] = *reinterpret_cast<const U4 *>(Win + ((((unsigned)ev[ci] >> 9) & (kWinRows - 1)) << 7) + lane_off);
-#else
       s.v[ci] = buf_load4u(r_xt, ev[ci] + lane_off, cbase2);
-#endif
-#endif
       s.w[ci] = __int_as_float(ev[NC + ci]);
     }
   };
@@ -273,55 +225,22 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) col[j] = 0.f;
 #pragma unroll
-#ifdef ABL_FWD_NOINTERP   // developer ablation (timing only): one corner instead of 2^ND
-    for (int ci = 0; ci < 1; ++ci) mac8<T>(col, s.v[ci], s.w[ci]);
-#else
     for (int ci = 0; ci < NC; ++ci) mac8<T>(col, s.v[ci], s.w[ci]);
-#endif
     *reinterpret_cast<U4 *>(bt_w + pg * 8 * kBtP) = pack8<T>(col);
   };
 
-#ifdef ABL_FWD_WINDOW
-  {
-    // rows of the (fictitious) window: 17 segments of 25 consecutive pixels, one image row apart, from the tile's
-    // first pixel on (clamped into the tensor); 8 lanes per row, 16 bytes each
-    const int n0w = min(tile * 128, g.N - 1);
-    const int b0w = n0w / g.S_o, p0w = n0w - b0w * g.S_o;
-    for (int i = tid; i < kWinFill * 8; i += 256) {
-      const int row = i >> 3, piece = i & 7;
-      const int q = min(max(p0w - 4 * g.in_sz[ND - 1] - 4 + (row / 25) * g.in_sz[ND - 1] + row % 25, 0), g.S_i - 1);
-      const U4 v = buf_load4u(r_xt, (b0w * g.S_i + q) * hd.Cp * 2 + piece * 16, ch_lo * 32);
-      *reinterpret_cast<U4 *>(Win + ((row & (kWinRows - 1)) << 7) + piece * 16) = v;
-    }
-    __syncthreads();
-  }
-#endif
   // ---- prologue ----
   int tap = 0, st = 0;                 // stage being processed
   int slot = 0;
-#if F2_PAIR
   int sig = 0;                         // index of the state being processed
   fetch_pair();
   build_pair(0);
   if (nstates > 2) fetch_pair();       // the pair after that
-#else
-  fetch(0, dg0);
-  build(0, 0);
-  {
-    // offsets / mask of the next state
-    const bool more_dg = g.DG > 1 && spd < nst;
-    if (more_dg) fetch(0, dg0 + 1);
-    else if (g.K > 1) fetch(1, dg0);
-  }
-#endif
   w_load(0, ch_lo);
   Set sa, sb;
   const int *st_lane = St + gp * SW;   // this lane's row of pixel group 0, slot 0
   issue(sa, st_lane, 0, ch_lo * 32);
   const int S = g.K * nst;
-#ifdef F2_TIMING
-  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
-#endif
   for (int s = 0; s < S; ++s) {
     const int ch0 = ch_lo + st * kStage;
     U4 *Ab = As + ((s & 1) * kStage * nmax) * 64 + lane;
@@ -330,7 +249,6 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     if (st1 == nst) { st1 = 0; ++tap1; }
     const bool new_state = st1 == 0 || (g.DG > 1 && st1 % spd == 0);
     int slot_next = slot;
-#if F2_PAIR
     if (new_state && s + 1 < S) {
       ++sig;
       slot_next = sig - (sig / 3) * 3;
@@ -339,17 +257,6 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
         if (sig + 2 < nstates) fetch_pair();
       }
     }
-#else
-    if (new_state && s + 1 < S) {
-      slot_next = slot ^ 1;
-      build(tap1, slot_next);
-      // offsets / mask of the state after that
-      int st2 = st1 + spd, tap2 = tap1;
-      if (st2 >= nst) { st2 = 0; ++tap2; }
-      if (tap2 < g.K) fetch(tap2, dg0 + st2 / spd);
-    }
-#endif
-    F2_T(0);   // next sampling state (build) + offset / mask fetch
     const int *sp_cur = st_lane + slot * 32 * SW;
     // ---- gather + interpolate the 4 pixel groups of this stage; the first group of the next stage
     // is requested before the matrix phase ----
@@ -357,31 +264,21 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
     interp(sa, 0);
     issue(sa, sp_cur, 2, ch0 * 32);
     interp(sb, 1);
-#ifndef F2_NO_EARLY_USE
     // the offsets / mask fetched at the top of this stage are OLDER than the gathers interp(sb, 1) has just waited
     // for: naming them as used here costs no wait, and build() of the next state does not have to drain the queue
 #pragma unroll
     for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(dlr[a]));
     if (MOD) asm volatile("" : "+v"(mlr));
-#endif
     issue(sb, sp_cur, 3, ch0 * 32);
     interp(sa, 2);
     if (s + 1 < S) issue(sa, st_lane + slot_next * 32 * SW, 0, (ch_lo + st1 * kStage) * 32);
     interp(sb, 3);
-    F2_T(1);   // gathers + interpolation of the 4 pixel groups
     // ---- weights of this stage -> LDS; next stage's weights requested ----
     w_store(Ab, ch0);
-    F2_T(2);   // weights -> LDS (waits for their loads)
     __syncthreads();
-    F2_T(3);   // barrier
     if (s + 1 < S) w_load(tap1, ch_lo + st1 * kStage);
-    F2_T(4);   // weight load issue
     // ---- matrix phase ----
-#ifdef ABL_FWD_NOMFMA   // developer ablation (timing only): no matrix phase (and no A / B fragment reads)
-    const int nj = 0;
-#else
     const int nj = min(kStage, ch_hi - ch0);
-#endif
 #pragma unroll
     for (int j = 0; j < kStage; ++j) {
       if (j < nj) {
@@ -398,7 +295,6 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
         }
       }
     }
-    F2_T(5);   // matrix phase
     slot = slot_next;
     tap = tap1;
     st = st1;
@@ -425,34 +321,14 @@ __global__ __launch_bounds__(256, 2) void hp_fwd2_kernel(
         if (o < g.O) T::stf(output + ((int64_t)b * g.O + o) * g.S_o + pix, acc[ob][r]);
       }
   }
-#ifdef F2_TIMING
-  F2_T(6);   // epilogue
-  if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_f2_timing[i], t_acc[i]);
-#endif
 }
 
 }  // namespace
 
-#ifdef F2_TIMING
-}  // namespace mdconv
-extern "C" void mdconv_debug_timing_f2(unsigned long long *out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdconv::g_f2_timing), sizeof(mdconv::g_f2_timing));
-  if (reset) {
-    unsigned long long z[8] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(mdconv::g_f2_timing), z, sizeof(z));
-  }
-}
-namespace mdconv {
-#endif
 
 size_t hp_fwd2_lds_bytes(const Geom &g, const HpDims &hd) {
   const int nc = 1 << g.nd;
-#ifdef ABL_FWD_WINDOW
-  const size_t win = 256 * 128;
-#else
   const size_t win = 0;
-#endif
   return (size_t)2 * kStage * (g.G == 1 ? hd.MB : hd.fwd_nmax) * 1024 + (size_t)4 * 32 * kBtP * 2 + (size_t)4 * kStSlots * 32 * 2 * nc * 4 + win;
 }
 

@@ -22,6 +22,7 @@ namespace mdconv {
 static thread_local char g_err[512] = "";
 static thread_local int g_last_path = 0;
 static thread_local int g_last_kernels = 0;
+// ABI v1 call modes (descriptors without MDCONV_DESC_V2); v2 descriptors carry their own
 static thread_local int g_accumulate = 1;
 static thread_local int g_input_layout = 0;   // MDCONV_LAYOUT_*
 // "grad_weight / grad_bias are final" events: one per (device, producer stream), shared by all
@@ -65,13 +66,43 @@ static int current_path() {
   return p;
 }
 
+static int desc_ndim(const mdconv_desc *d) { return d->ndim & ~MDCONV_DESC_V2; }
+
+// Call modes of one call: from the descriptor (ABI v2) or from the v1 setters of the calling thread / process.
+struct Modes { int accumulate, input_layout, path; };
+static int call_modes(const mdconv_desc *d, Modes *m) {
+  if (!(d->ndim & MDCONV_DESC_V2)) {
+    m->accumulate = g_accumulate;
+    m->input_layout = g_input_layout;
+    m->path = current_path();
+    return MDCONV_OK;
+  }
+  if ((d->accumulate != 0 && d->accumulate != 1) ||
+      (d->input_layout != MDCONV_LAYOUT_NCHW && d->input_layout != MDCONV_LAYOUT_CHANNELS_LAST) ||
+      d->path < MDCONV_PATH_AUTO || d->path > MDCONV_PATH_MFMA) {
+    set_error("bad call mode in the descriptor (accumulate=%d, input_layout=%d, path=%d)", d->accumulate,
+              d->input_layout, d->path);
+    return MDCONV_EINVAL;
+  }
+  for (int i = 0; i < 5; ++i)
+    if (d->reserved[i] != 0) {
+      set_error("mdconv_desc.reserved must be 0");
+      return MDCONV_EINVAL;
+    }
+  m->accumulate = d->accumulate;
+  m->input_layout = d->input_layout;
+  m->path = d->path == MDCONV_PATH_AUTO ? current_path() : d->path;
+  return MDCONV_OK;
+}
+
 int fill_geom(const mdconv_desc *d, Geom *g) {
   if (!d) {
     set_error("descriptor is NULL");
     return MDCONV_ENULL;
   }
-  if (d->ndim != 2 && d->ndim != 3) {
-    set_error("ndim must be 2 or 3 (got %d)", d->ndim);
+  const int ndim = desc_ndim(d);
+  if (ndim != 2 && ndim != 3) {
+    set_error("ndim must be 2 or 3 (got %d)", ndim);
     return MDCONV_EINVAL;
   }
   if (d->dtype != MDCONV_F32 && d->dtype != MDCONV_F16 && d->dtype != MDCONV_F64 &&
@@ -97,7 +128,7 @@ int fill_geom(const mdconv_desc *d, Geom *g) {
     return MDCONV_EINVAL;
   }
   memset(g, 0, sizeof(*g));
-  g->nd = d->ndim;
+  g->nd = ndim;
   g->B = d->batch;
   g->C = d->c_in;
   g->O = d->c_out;
@@ -105,7 +136,7 @@ int fill_geom(const mdconv_desc *d, Geom *g) {
   g->DG = d->dgroups;
   int64_t S_i = 1, S_o = 1, K = 1;
   for (int a = 0; a < 3; ++a) {
-    const bool used = a < d->ndim;
+    const bool used = a < ndim;
     const int n = used ? d->in_sz[a] : 1, k = used ? d->k_sz[a] : 1, s = used ? d->stride[a] : 1;
     const int p = used ? d->pad[a] : 0, dl = used ? d->dil[a] : 1;
     if (n <= 0 || k <= 0 || s <= 0 || dl <= 0 || p < 0) {
@@ -144,8 +175,8 @@ int fill_geom(const mdconv_desc *d, Geom *g) {
   g->modulated = d->modulated ? 1 : 0;
   g->acc_data = g->acc_w = 1;
   // gating flavours of the four reference files
-  const bool mdcn2d = d->ndim == 2 && d->modulated;
-  const bool dcn2d = d->ndim == 2 && !d->modulated;
+  const bool mdcn2d = ndim == 2 && d->modulated;
+  const bool dcn2d = ndim == 2 && !d->modulated;
   g->load_eps = mdcn2d ? 0 : 1;
   g->atom_eps = dcn2d ? 0 : 1;
   g->range_gate = mdcn2d ? 1 : 0;
@@ -155,9 +186,9 @@ int fill_geom(const mdconv_desc *d, Geom *g) {
 // One line on stderr, once per process, when a shape with matrix-sized channel counts runs on the
 // shape-generic VALU kernels (an order of magnitude slower than the matrix-core kernels): nothing else tells the user
 // (mdconv_last_kernels() reports it per call; MDCONV_QUIET=1 silences the line).
-static void note_direct_fallback(const Geom &g, int dtype, bool backward) {
+static void note_direct_fallback(const Geom &g, int dtype, bool backward, int path) {
   static std::atomic<bool> said{false};
-  if (g.Cg < 16 || g.Og < 16 || dtype == MDCONV_F64 || current_path() == MDCONV_PATH_DIRECT) return;
+  if (g.Cg < 16 || g.Og < 16 || dtype == MDCONV_F64 || path == MDCONV_PATH_DIRECT) return;
   if (!backward && g.Cg < 64) return;   // narrow conv groups: the shape-generic forward is no slower (mfma_kernels.hip)
   if (said.exchange(true)) return;
   const char *q = getenv("MDCONV_QUIET");
@@ -197,19 +228,21 @@ static int run_forward(const mdconv_desc *d, int nd, int modulated, Tensors t, v
   Geom g;
   int rc = fill_geom(d, &g);
   if (rc) return rc;
-  if (d->ndim != nd || (d->modulated != 0) != (modulated != 0)) {
-    set_error("descriptor (ndim=%d, modulated=%d) does not match this entry point", d->ndim,
+  if (g.nd != nd || (d->modulated != 0) != (modulated != 0)) {
+    set_error("descriptor (ndim=%d, modulated=%d) does not match this entry point", g.nd,
               d->modulated);
     return MDCONV_EINVAL;
   }
+  Modes md;
+  if ((rc = call_modes(d, &md))) return rc;
   if ((rc = require(t.input, "input")) || (rc = require(t.weight, "weight")) ||
       (rc = require(t.offset, "offset")) || (rc = require(t.output, "output")))
     return rc;
   if (modulated && (rc = require(t.mask, "mask"))) return rc;
   if (g.with_bias && (rc = require(t.bias, "bias"))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int path = current_path();
-  g.in_cl = g_input_layout == MDCONV_LAYOUT_CHANNELS_LAST ? 1 : 0;
+  const int path = md.path;
+  g.in_cl = md.input_layout == MDCONV_LAYOUT_CHANNELS_LAST ? 1 : 0;
   if (g.in_cl && !(path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, false) && g.C % 32 == 0)) {
     set_error("channels-last input is only supported by the native 16-bit kernels with C_in a multiple of 32");
     return MDCONV_EUNSUPPORTED;
@@ -235,7 +268,7 @@ static int run_forward(const mdconv_desc *d, int nd, int modulated, Tensors t, v
   }
   g_last_path = MDCONV_PATH_DIRECT;
   g_last_kernels = MDCONV_KERNELS_DIRECT;
-  note_direct_fallback(g, d->dtype, false);
+  note_direct_fallback(g, d->dtype, false, path);
   return direct_forward(g, d->dtype, t, s);
 }
 
@@ -245,11 +278,13 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
   Geom g;
   int rc = fill_geom(d, &g);
   if (rc) return rc;
-  if (d->ndim != nd || (d->modulated != 0) != (modulated != 0)) {
-    set_error("descriptor (ndim=%d, modulated=%d) does not match this entry point", d->ndim,
+  if (g.nd != nd || (d->modulated != 0) != (modulated != 0)) {
+    set_error("descriptor (ndim=%d, modulated=%d) does not match this entry point", g.nd,
               d->modulated);
     return MDCONV_EINVAL;
   }
+  Modes md;
+  if ((rc = call_modes(d, &md))) return rc;
   if ((rc = require(t.input, "input")) || (rc = require(t.weight, "weight")) ||
       (rc = require(t.offset, "offset")) || (rc = require(t.grad_output, "grad_output")) ||
       (rc = require(t.grad_input, "grad_input")) || (rc = require(t.grad_weight, "grad_weight")) ||
@@ -259,9 +294,9 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
     return rc;
   if (g.with_bias && (rc = require(t.grad_bias, "grad_bias"))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  g.acc_data = g.acc_w = g_accumulate;
-  const int path = current_path();
-  g.in_cl = g_input_layout == MDCONV_LAYOUT_CHANNELS_LAST ? 1 : 0;
+  g.acc_data = g.acc_w = md.accumulate;
+  const int path = md.path;
+  g.in_cl = md.input_layout == MDCONV_LAYOUT_CHANNELS_LAST ? 1 : 0;
   if (g.in_cl && !(path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, true) && g.C % 32 == 0)) {
     set_error("channels-last input is only supported by the native 16-bit kernels with C_in a multiple of 32");
     return MDCONV_EUNSUPPORTED;
@@ -285,13 +320,13 @@ static int run_backward(const mdconv_desc *d, int nd, int modulated, Tensors t, 
   }
   g_last_path = MDCONV_PATH_DIRECT;
   g_last_kernels = MDCONV_KERNELS_DIRECT;
-  note_direct_fallback(g, d->dtype, true);
+  note_direct_fallback(g, d->dtype, true, path);
   if (d->dtype == MDCONV_F16 || d->dtype == MDCONV_BF16) {
     if ((rc = check_ws(ws, ws_bytes, direct16_workspace_bytes(g)))) return rc;
     if ((rc = direct16_backward(g, d->dtype, t, ws, s))) return rc;
     return record_weight_ready(s);
   }
-  if (!g_accumulate) {
+  if (!md.accumulate) {
     // the direct kernels scatter with atomics, so "overwrite" means: clear first
     const size_t es = d->dtype == MDCONV_F64 ? 8 : (d->dtype == MDCONV_F32 ? 4 : 2);
     const size_t n_off = (size_t)g.B * g.DG * g.nd * g.K * g.S_o, n_m = (size_t)g.B * g.DG * g.K * g.S_o;
@@ -375,17 +410,18 @@ const char *mdconv_last_error(void) { return g_err; }
 
 int mdconv_out_size(const mdconv_desc *d, int axis) {
   if (!d || axis < 0 || axis > 2) return -1;
-  if (axis >= d->ndim) return 1;
+  if (axis >= desc_ndim(d)) return 1;
   return (d->in_sz[axis] + 2 * d->pad[axis] - (d->dil[axis] * (d->k_sz[axis] - 1) + 1)) /
              d->stride[axis] + 1;
 }
 
 size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward) {
   Geom g;
-  if (fill_geom(d, &g)) return 0;
+  Modes md;
+  if (fill_geom(d, &g) || call_modes(d, &md)) return 0;
   const bool half = d->dtype == MDCONV_F16 || d->dtype == MDCONV_BF16;
   const size_t direct = backward && half ? direct16_workspace_bytes(g) : 0;   // fp32 copies for the scatter kernels
-  if (current_path() == MDCONV_PATH_DIRECT) return direct;
+  if (md.path == MDCONV_PATH_DIRECT) return direct;
   if (hp_supported(g, d->dtype, backward != 0)) {
     const size_t hp = hp_workspace_bytes(g, d->dtype, backward != 0);
     if (backward || hp_forward_preferred(g, d->dtype)) return hp;
@@ -406,10 +442,11 @@ int mdconv_set_input_layout(int layout) {
 
 int mdconv_input_layout_supported(const mdconv_desc *d, int layout, int backward) {
   Geom g;
-  if (fill_geom(d, &g)) return 0;
+  Modes md;
+  if (fill_geom(d, &g) || call_modes(d, &md)) return 0;
   if (layout == MDCONV_LAYOUT_NCHW) return 1;
   if (layout != MDCONV_LAYOUT_CHANNELS_LAST) return 0;
-  return current_path() != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, backward != 0) && g.C % 32 == 0;
+  return md.path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, backward != 0) && g.C % 32 == 0;
 }
 
 int mdconv_set_accumulate(int on) {

@@ -32,6 +32,8 @@
 #include "mfma_kernels.hpp"
 #include "mfma_tile.hpp"
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -48,11 +50,10 @@ int grid_for(int64_t total) {
 //                                                      [cblk*32 + (lane&31)][tap]   (0 padded)
 // With groups the weight is expanded to its dense block-diagonal form (0 where o and c belong to
 // different groups); GEMM-1 then only walks the o-chunks that can be non-zero for its channels.
-__global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int cblks,
-                                                      const float *__restrict__ w,
-                                                      float *__restrict__ wq) {
+__device__ __forceinline__ void pack_wq_items(const Geom &g, int ochunks, int cblks, const float *__restrict__ w,
+                                              float *__restrict__ wq, int64_t first, int64_t step) {
   const int64_t total = (int64_t)g.K * ochunks * cblks * 2 * 64;   // float4 units
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = first; i < total; i += step) {
     int64_t r = i;
     const int lane = (int)(r & 63); r >>= 6;
     const int q = (int)(r & 1); r >>= 1;
@@ -72,6 +73,12 @@ __global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int c
   }
 }
 
+__global__ __launch_bounds__(256) void pack_wq_kernel(Geom g, int ochunks, int cblks,
+                                                      const float *__restrict__ w,
+                                                      float *__restrict__ wq) {
+  pack_wq_items(g, ochunks, cblks, w, wq, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+
 // pack_wq + counter clearing + channels-last input copy in one launch (roles by block range; see bwd_prep_f32)
 __global__ __launch_bounds__(256) void bwd_prep_kernel(Geom g, int ochunks, int cblks, const float *__restrict__ w,
                                                        float *__restrict__ wq, int *__restrict__ cnt, int64_t cnt_n,
@@ -80,25 +87,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(Geom g, int ochunks, int 
   __shared__ float t[32][33];
   int bid = blockIdx.x;
   if (bid < nb_pack) {
-    const int64_t total = (int64_t)g.K * ochunks * cblks * 2 * 64;   // float4 units (pack_wq_kernel)
-    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < total; i += (int64_t)nb_pack * 256) {
-      int64_t r = i;
-      const int lane = (int)(r & 63); r >>= 6;
-      const int q = (int)(r & 1); r >>= 1;
-      const int cblk = (int)(r % cblks); r /= cblks;
-      const int ochunk = (int)(r % ochunks);
-      const int tap = (int)(r / ochunks);
-      const int c = cblk * 32 + (lane & 31);
-      const int ob = ochunk * 16 + 8 * q + 4 * (lane >> 5);
-      float v[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int o = ob + s;
-        v[s] = (o < g.O && c < g.C && o / g.Og == c / g.Cg)
-                   ? w[((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap] : 0.f;
-      }
-      reinterpret_cast<float4 *>(wq)[i] = make_float4(v[0], v[1], v[2], v[3]);
-    }
+    pack_wq_items(g, ochunks, cblks, w, wq, (int64_t)bid * 256 + threadIdx.x, (int64_t)nb_pack * 256);
     return;
   }
   bid -= nb_pack;
@@ -147,19 +136,9 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(Geom g, int ochunks, int 
 // CL: the drain gathers from the channels-last input copy xt[b][q][c] (mfma_fwd_cl.hip): a lane
 // fetches 4 consecutive channels of ONE corner of its pixel with a 16-byte load -- half the load
 // instructions of the paired NCHW loads and, in 3-D, a third of the cache lines.
-#ifdef B1_TIMING
-// developer instrumentation (tools/b1_timing.py): cycles per phase of the main loop, summed over all waves
-__device__ unsigned long long g_b1_timing[12];
-#define B1_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define B1_T(slot) do { } while (0)
-#endif
 
-#ifndef B1_MINWAVES
-#define B1_MINWAVES 2
-#endif
 template <int ND, bool MOD, int WAVES_C, int QPQ, bool CL>
-__global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
+__global__ __launch_bounds__(256, 2) void mfma_bwd_data_kernel(
     Geom g, BwdDims bd, const float *__restrict__ input, const float *__restrict__ gout,
     const float *__restrict__ wq, const float *__restrict__ offset, const float *__restrict__ mask,
     float *__restrict__ gcol, float *__restrict__ grad_offset, float *__restrict__ grad_mask,
@@ -267,9 +246,6 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
 
   // ---- the pixel this lane owns in the accumulator layout: of the tile whose K loop runs
   // (`c`) and of the tile whose accumulators are parked (`p`) ----
-#ifdef B1_TIMING
-  unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
-#endif
   struct Pix { int n0, b, pix; bool live; int oc[ND]; };
   auto pix_of_tile = [&](int tile, Pix &px) {
     px.n0 = tile * BNP;
@@ -528,11 +504,7 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
           const int o = st[c] + 16 * gl_j;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-#ifdef ABL_B1_NOGATHER   // developer ablation (timing only): no corner loads in the channels-last drain
-            const float4 x = make_float4((float)o, 1.f, 2.f, 3.f);
-#else
             const float4 x = buf_load4(r_in, o + 64 * k, cbase_p * 4);
-#endif
             float *d = v.f + (c * 4 + k) * 4;
             d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
           }
@@ -574,11 +546,7 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         gc[k] = *reinterpret_cast<const float4 *>(Pk + pxl * 64 + 4 * ((4 * k + gl_j) ^ swz));
-#ifdef ABL_B1_NOSTORE   // developer ablation (timing only): grad_col rows are (practically) never written
-      if (cp == 0 && gc[0].x == 1.2345e30f) {
-#else
       if (cp == 0) {   // grad_col row: the quad stores 64 contiguous bytes per instruction
-#endif
         const int gv = st[NC] + 16 * gl_j;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -747,11 +715,7 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       for (int a = 0; a < ND; ++a) rp[a * BNP] = goff[a];
       rp[ND * BNP] = gm;
     }
-#ifdef ABL_B1_NOFLUSH   // developer ablation (timing only): no workgroup-wide flush of the grad_offset / grad_mask partials
-    if (false) {
-#else
     if (flush_ok && (slot == kTapGroup - 1 || tapp == g.K - 1 || last)) {
-#endif
       __syncthreads();
       // single owner of every (b, dg, tap, pix): plain read-modify-write (or write, mdconv_set_accumulate)
       const int tap0 = tapp - slot;
@@ -783,38 +747,6 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     const float4 b0 = *reinterpret_cast<const float4 *>(bp);
     const float4 b1 = *reinterpret_cast<const float4 *>(bp + 8);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#ifdef ABL_B1_BF16X3
-    // Developer ablation (TIMING ONLY, results are wrong): the instruction mix of a three-term bf16 split of this chunk's
-    // K = 16 product -- the 8 grad_out values of the lane split into hi / mid / lo bf16 planes on the fly (real code), six
-    // v_mfma_f32_32x32x16_bf16 per 32-channel block instead of eight v_mfma_f32_32x32x2_f32, the A planes faked from the
-    // fp32 fragments that are loaded anyway (a real kernel would load 1.5x the A bytes): an upper bound on what the
-    // verdict's opt-in item 5 can buy in this kernel structure.
-    {
-      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-      const float bx[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      bf16x8_t bh, bm, bl;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)bx[j];
-        const float r = bx[j] - (float)h;
-        const __bf16 m = (__bf16)r;
-        const __bf16 l = (__bf16)(r - (float)m);
-        bh[j] = h; bm[j] = m; bl[j] = l;
-      }
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, ra[i][0]);
-        const bf16x8_t am = __builtin_bit_cast(bf16x8_t, ra[i][1]);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, fresh ? zero : acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bl, acc[i], 0, 0, 0);
-      }
-      return;
-    }
-#endif
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -856,21 +788,15 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       if (per_block) new_tap_state(tapp, min(blk * 64, g.C - 1) / g.Cdg, blk % bpd == 0 && blk * 64 < g.C);
       else new_tap_state(tapp, 0, wc == 0);
     }
-    B1_T(0);   // tap state of the parked tap
     if (tile != tile_c) {
       if (tile_c >= 0) __syncthreads();   // every wave is done with the previous tile's K loops
-      B1_T(8);   // barrier: previous tile done
       if (gout_vec) load_gout_tile_vec(tile);
       else load_gout_tile(tile);
       pix_of_tile(tile, pc);
       tile_c = tile;
-      B1_T(9);   // grad_out tile: global loads -> LDS
       __syncthreads();
-      B1_T(10);  // barrier: tile complete
       if (tap == 0 && pass == 0) emit_ga(tile);
-      B1_T(11);  // ga emission, grad_bias partials
     }
-    B1_T(1);
     if (pass == 0 || per_block) {
       const int dg = per_block ? min((pass * WAVES_C + wc) * 64, g.C - 1) / g.Cdg : 0;
       const int64_t seg = (int64_t)pc.b * g.DG + dg;
@@ -905,12 +831,10 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
       Batch v;
       // straight-line path: the A fragment of chunk t+3 is requested BEFORE the gathers, so only
       // the fragment of chunk t+4 (needed four chunks later) queues behind them
-      B1_T(2);   // offsets / stream bookkeeping (first batch), loop overhead
       if (QPQ > 0) quad_head(q * QPQ * 4);
       gather(q, cbase_p, v);
       asm volatile("" ::: "memory");   // IR-level fence: keep batch q's gathers here
       __builtin_amdgcn_sched_barrier(0);
-      B1_T(3);   // gather issue
       if (QPQ > 0) {
         quad_tail(q * QPQ * 4, q == 0);
 #pragma unroll
@@ -919,11 +843,9 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
         for (int qd = nq * q / NBATCH; qd < nq * (q + 1) / NBATCH; ++qd) quad(qd * 4, false);
       }
       __builtin_amdgcn_sched_barrier(0);
-      B1_T(4);   // MFMA quads (A fragment loads, LDS B reads)
       consume(q, cbase_p, v);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      B1_T(5);   // consume: wait for the gathers, corner sums, grad_col rows
     }
     // the parked tap is complete after its last pass (per block: after every pass); its group is
     // flushed at a group / tile end
@@ -931,7 +853,6 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     if (it > 0 && (passp == passes - 1 || per_block))
       finish_tap(tapp, per_block ? passp * WAVES_C + wc : wc, passp == passes - 1, false);
     park();
-    B1_T(6);   // collect / finish_tap / park
     pp = pc;
     tapp = tap;
     passp = pass;
@@ -967,26 +888,8 @@ __global__ __launch_bounds__(256, B1_MINWAVES) void mfma_bwd_data_kernel(
     collect();
     finish_tap(tapp, per_block ? passp * WAVES_C + wc : wc, true, true);
   }
-#ifdef B1_TIMING
-  B1_T(7);   // drain of the last iteration
-  if (lane == 0)
-    for (int i = 0; i < 12; ++i) atomicAdd(&g_b1_timing[i], t_acc[i]);
-#endif
 }
 
-#ifdef B1_TIMING
-}  // namespace
-}  // namespace mdconv
-extern "C" void mdconv_debug_timing_b1(unsigned long long *out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdconv::g_b1_timing), sizeof(mdconv::g_b1_timing));
-  if (reset) {
-    unsigned long long z[12] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(mdconv::g_b1_timing), z, sizeof(z));
-  }
-}
-namespace mdconv {
-namespace {
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // 2. inverse scatter map (CSR keyed by (image, deformable group, input pixel))
@@ -1362,24 +1265,33 @@ int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const 
     const int bnp = 32 * (4 / WC);                                                              \
     const int ntiles = (g.N + bnp - 1) / bnp;                                                   \
     const size_t lds = bwd_data_lds_bytes(g, bd);                                               \
-    if (lds > 64 * 1024) {                                                                      \
-      hipError_t ea = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (ea != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(ea)); return MDCONV_ELAUNCH; } \
-    }                                                                                           \
+    /* Per-instance launch state, shared by every host thread that runs backwards (autograd workers,            */ \
+    /* tests/test_gpu_concurrency.py): the dynamic-LDS limit is raised ONCE to the cap mfma_supported() enforces */ \
+    /* (a per-launch attribute could be lowered by one thread under another's launch), and the resident-workgroup */ \
+    /* count is cached per LDS size (it varies with C_out and K for one instance) under a mutex.                  */ \
+    static std::once_flag attr_once;                                                            \
+    static hipError_t attr_err = hipSuccess;                                                    \
+    std::call_once(attr_once, [] {                                                              \
+      attr_err = hipFuncSetAttribute((const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>,  \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdDataLdsCap); \
+    });                                                                                         \
+    if (attr_err != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_err)); return MDCONV_ELAUNCH; } \
     /* complete dispatch rounds of one-tile workgroups (2 per CU by registers, fewer by LDS),  */ \
     /* then the units of the leftover tiles spread over one more, shorter, round              */ \
-    /* resident workgroups per CU of this instance at THIS dynamic LDS size (it varies with C_out and K for  */ \
-    /* one instance: re-queried when the size changes -- advisor, round 4)                                      */ \
-    static int occ_q = 0;                                                                       \
-    static size_t occ_lds = 0;                                                                  \
-    if (occ_q == 0 || occ_lds != lds) {   /* (unsynchronised: a race only mis-sizes one launch's rounds) */ \
-      int nq = 0;                                                                               \
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                       \
-          &nq, (const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, 256, lds);       \
-      (void)hipGetLastError();                                                                  \
-      occ_q = nq > 0 ? nq : (lds * 2 <= 160 * 1024 ? 2 : 1);                                    \
-      occ_lds = lds;                                                                            \
+    int occ_q = 0;                                                                              \
+    {                                                                                           \
+      static std::mutex occ_mu;                                                                 \
+      static std::map<size_t, int> occ_by_lds;                                                  \
+      std::lock_guard<std::mutex> lock(occ_mu);                                                 \
+      auto it = occ_by_lds.find(lds);                                                           \
+      if (it == occ_by_lds.end()) {                                                             \
+        int nq = 0;                                                                             \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                     \
+            &nq, (const void *)mfma_bwd_data_kernel<ND, MOD, WC, QPQ, CL>, 256, lds);           \
+        (void)hipGetLastError();                                                                \
+        it = occ_by_lds.emplace(lds, nq > 0 ? nq : (lds * 2 <= 160 * 1024 ? 2 : 1)).first;      \
+      }                                                                                         \
+      occ_q = it->second;                                                                       \
     }                                                                                           \
     const int slots = num_cus() * occ_q;                                                        \
     const int tpw = 2;   /* whole tiles per workgroup of the full rounds */                     \

@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_kernel(Geom g, BwdDims bd
   auto gather = [&](const Tab &tb) {
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
-      const int vo = (tb.vo[pi] & ~3) + chan_voff;
+      // unsigned arithmetic: a parked pair (0x7ffffff0, written by GEMM-1) plus the channel plane wraps past 2^31, which
+      // the buffer's bounds check reads as an out-of-range UNSIGNED offset (loads give 0) -- every per-chunk tensor stays
+      // below 2 GiB (chunk_limit(), mfma_kernels.hip), so no in-range sum can reach that value
+      const int vo = (int)(((unsigned)tb.vo[pi] & ~3u) + (unsigned)chan_voff);
 #pragma unroll
       for (int i = 0; i < CT; ++i) rg[i][pi] = buf_load2(r_in, vo, i * chan_soff);
     }

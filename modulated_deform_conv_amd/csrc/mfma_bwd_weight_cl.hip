@@ -21,13 +21,6 @@ namespace mdconv {
 
 namespace {
 
-#ifdef B2_TIMING
-// developer instrumentation (tools/b1_timing.py --gemm2): cycles per phase of the chunk loop, summed over all waves
-__device__ unsigned long long g_b2_timing[8];
-#define B2_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define B2_T(slot) do { } while (0)
-#endif
 
 // <WR, WC, MB, NBW>: WR x WC waves, each MB x NBW blocks of 32 x 32; WC * NBW * 32 == 64
 //   <4, 1, 2, 2>  256 x 64   (the narrow tiles -- 64 x 64, 128 x 64 for C_out <= 64 / 128 -- run the 64-pixel-slab
@@ -161,9 +154,6 @@ __global__ __launch_bounds__(256, 1) void mfma_bwd_weight_cl_kernel(Geom g, BwdD
       }
   };
 
-#ifdef B2_TIMING
-  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
-#endif
   if (t_begin < t_end) {
     const int t_last = t_end - 1;
     Tab tabA, tabB;
@@ -172,48 +162,23 @@ __global__ __launch_bounds__(256, 1) void mfma_bwd_weight_cl_kernel(Geom g, BwdD
     load_tab(tabB, t_begin + 1);
     load_a(ra0, t_begin);
     gather(tabA);
-    B2_T(0);   // prologue
     for (int t = t_begin; t < t_end; t += 2) {
       // ---- even chunk ----
-#ifdef B2_A_EARLY   // (experiment: A fragments requested before the slab hand-over -- GEMM-2 1.10 -> 1.17 ms at cfg2)
-      load_a(ra1, t + 1);
-      B2_T(5);
-#endif
       commit(tabA, t, Bs);
-      B2_T(1);   // commit: wait for the gathers, blend, slab -> LDS
       __syncthreads();
-      B2_T(2);   // barrier
-#ifndef B2_A_EARLY
       load_a(ra1, t + 1);                   // A first: vmcnt retires in order (see mfma_fwd.hip)
-      B2_T(5);
-#endif
       gather(tabB);                         // chunk t+1
-      B2_T(6);
       load_tab(tabA, min(t + 2, t_last));   // chunk t+2
       __builtin_amdgcn_sched_barrier(0);
-      B2_T(3);   // load issue
       mma(ra0, Bs);
-      B2_T(4);   // MFMAs (A fragment wait, LDS B reads)
       // ---- odd chunk ----
-#ifdef B2_A_EARLY
-      load_a(ra0, min(t + 2, t_last));
-      B2_T(5);
-#endif
       commit(tabB, t + 1, Bs + BK * kPitch);
-      B2_T(1);
       __syncthreads();
-      B2_T(2);
-#ifndef B2_A_EARLY
       load_a(ra0, min(t + 2, t_last));
-      B2_T(5);
-#endif
       gather(tabA);                         // chunk t+2 (or a harmless repeat at the end)
-      B2_T(6);
       load_tab(tabB, min(t + 3, t_last));
       __builtin_amdgcn_sched_barrier(0);
-      B2_T(3);
       mma(ra1, Bs + BK * kPitch);
-      B2_T(4);
     }
   }
 
@@ -229,11 +194,6 @@ __global__ __launch_bounds__(256, 1) void mfma_bwd_weight_cl_kernel(Geom g, BwdD
         dst[(size_t)o * bd.Cp] = acc[mb][n][r];
       }
   }
-#ifdef B2_TIMING
-  B2_T(7);   // partial tile stores
-  if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_b2_timing[i], t_acc[i]);
-#endif
 }
 
 
@@ -432,17 +392,6 @@ __global__ __launch_bounds__(256) void mfma_bwd_weight_cl64_kernel(Geom g, BwdDi
 
 }  // namespace
 
-#ifdef B2_TIMING
-}  // namespace mdconv
-extern "C" void mdconv_debug_timing_b2(unsigned long long *out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdconv::g_b2_timing), sizeof(mdconv::g_b2_timing));
-  if (reset) {
-    unsigned long long z[8] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(mdconv::g_b2_timing), z, sizeof(z));
-  }
-}
-namespace mdconv {
-#endif
 
 // Resident workgroups per CU of the variant that (nd, padn, wtile, coord) selects: hipOccupancy on the very
 // instance, so the split-K count of bwd_dims() follows the register allocation instead of a constant that rots.

@@ -40,13 +40,6 @@
 namespace mdconv {
 
 namespace {
-#ifdef F1_TIMING
-// developer instrumentation (tools/b1_timing.py --fwd): cycles per phase of the chunk loop, summed over all waves
-__device__ unsigned long long g_f1_timing[8];
-#define F1_T(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define F1_T(slot) do { } while (0)
-#endif
 
 
 template <int ND, bool MOD, int BM, int BN, int WM, int WN, bool PADK>
@@ -191,20 +184,13 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
     for (int i = 0; i < CPT; ++i)
 #pragma unroll
       for (int pi = 0; pi < NP; ++pi) {
-#ifdef ABL_NOGATHER
-        rg[i][pi] = make_float2((float)(voff[pi] + soff), 1.f);
-#else
         rg[i][pi] = buf_load2(r_in, voff[pi], soff + i * g.S_i * 4);
-#endif
       }
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) { wc[ci] = wgt[ci]; bd[ci] = bad[ci]; }
   };
   // interpolate the gathered corners and publish the B slab of the chunk starting at channel c0
   auto commit = [&](const float2 (&rgl)[CPT][NP], const float (&wc)[NC], const lanemask_t (&bd)[NC], int c0, float *Bb) {
-#ifdef ABL_NOCOMMIT
-    return;
-#endif
     lanemask_t any_bad = 0ull;
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) any_bad |= bd[ci];
@@ -243,11 +229,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-#ifdef ABL_NOWEIGHT
-        ra[i][q] = make_float4(0.5f, 0.25f, 1.f, 2.f);
-#else
         ra[i][q] = buf_load4(r_wp, a_voff + (i * 2 + q) * 1024, soff);
-#endif
       }
   };
   auto mma = [&](const float4 (&ra)[MB][2], const float *Bbuf) {
@@ -258,21 +240,13 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       for (int s = 0; s < 4; ++s) {
         float b[NB];
 #pragma unroll
-#ifdef ABL_NOLDSREAD
-        for (int n = 0; n < NB; ++n) b[n] = 0.25f * (float)(lane + s);
-#else
         for (int n = 0; n < NB; ++n) b[n] = Bb[(8 * q + s) * BN + n * 32];
-#endif
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
           const float a = s == 0 ? ra[i][q].x : (s == 1 ? ra[i][q].y : (s == 2 ? ra[i][q].z : ra[i][q].w));
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-#ifdef ABL_NOMFMA
-            acc[i][n][s] += a * b[n];
-#else
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[i][n], 0, 0, 0);
-#endif
         }
       }
   };
@@ -286,13 +260,9 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
   float4 ra0[MB][2], ra1[MB][2];
   const int a_last = (T - 1) * slab_bytes;
   int a_soff = tap_lo * cchunks * slab_bytes;   // byte offset of the current chunk in the packed weights
-#ifdef F1_TIMING
-  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
-#endif
   load_a(ra0, a_soff);
   issue(rg0, wc0, bad0, tap_lo, 0);
   issue(rg1, wc1, bad1, tap_lo, BK);
-  F1_T(0);   // prologue
   for (int tap = tap_lo; tap < tap_hi; ++tap) {
     for (int c0 = 0; c0 < pd.Cgp; c0 += 2 * BK) {
       // position of the chunk pair two chunks ahead (past the end: harmless re-request)
@@ -301,35 +271,21 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
       const int nc0 = wrap ? 0 : c0 + 2 * BK;
       // ---- even chunk: LDS buffer 0, fragments ra0, gathers rg0 ----
       commit(rg0, wc0, bad0, c0, Bs);
-      F1_T(1);   // commit: wait for the gathers, interpolate, slab -> LDS
-#ifndef ABL_NOBARRIER
       __syncthreads();
-#endif
-      F1_T(2);   // barrier
       // A first: vmcnt retires in order, so fragments requested AFTER the gathers would make the
       // MFMAs that need them wait for those gathers as well
       load_a(ra1, a_soff + slab_bytes);
-      F1_T(3);   // A issue
       issue(rg0, wc0, bad0, ntap, nc0);
       __builtin_amdgcn_sched_barrier(0);   // keep every request above the MFMA phase
-      F1_T(4);   // gather issue (+ sampling state on a tap change)
       mma(ra0, Bs);
-      F1_T(5);   // MFMAs
       // ---- odd chunk: LDS buffer 1, fragments ra1, gathers rg1 ----
       commit(rg1, wc1, bad1, c0 + BK, Bs + BK * BN);
-      F1_T(1);
-#ifndef ABL_NOBARRIER
       __syncthreads();
-#endif
-      F1_T(2);
       a_soff += 2 * slab_bytes;
       load_a(ra0, min(a_soff, a_last));
-      F1_T(3);
       issue(rg1, wc1, bad1, ntap, nc0 + BK);
       __builtin_amdgcn_sched_barrier(0);
-      F1_T(4);
       mma(ra1, Bs + BK * BN);
-      F1_T(5);
     }
   }
 
@@ -364,11 +320,6 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(Geom g, PackDims pd,
         }
     }
   }
-#ifdef F1_TIMING
-  F1_T(6);   // epilogue
-  if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_f1_timing[i], t_acc[i]);
-#endif
 }
 
 // output tile of a tail tile = sum of its tap-range partials (+ bias), in a fixed order
@@ -514,17 +465,6 @@ int launch_fwd(const Geom &g, const PackDims &pd, const Tensors &t, const float 
 
 }  // namespace
 
-#ifdef F1_TIMING
-}  // namespace mdconv
-extern "C" void mdconv_debug_timing_f1(unsigned long long *out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdconv::g_f1_timing), sizeof(mdconv::g_f1_timing));
-  if (reset) {
-    unsigned long long z[8] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(mdconv::g_f1_timing), z, sizeof(z));
-  }
-}
-namespace mdconv {
-#endif
 
 // scratch for the tap-range partials of the tail tiles: at most one partial tile (every tile shape is 8192
 // floats) per resident workgroup, 5 of them per CU at the very most

@@ -163,36 +163,36 @@ BwdDims bwd_dims(const Geom &g) {
   // channels -- the extra ones own zero-padded channel blocks and idle through the drain -- and the pixel tile shrinks
   // with them.  Half the matrix rate of GEMM-1 at such shapes, against the shape-generic kernels they used to fall to (~10x).
   for (;;) {
-  bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
-  // GEMM-1 drain: channels-last (line-wide gathers through an LDS hand-over, mfma_bwd_data.hip)
-  // whenever the backward has the channels-last copy -- except for straight-line 2-D shapes whose
-  // LDS (grad_out tile + parked accumulators) would then allow only one workgroup per CU
-  // (C_in = 128, C_out = 256: 1.56 -> 1.70 ms).  MDCONV_BD_CL = 0 / 1 overrides.
-  // Reduction buffer [tap group][64-channel blocks to reduce][nd + 1][pixels of the tile]: groups of
-  // 3 taps instead of 9 where that keeps the kernel under 80 KB of LDS (two workgroups per CU).
-  const int red_per_tap = 128 * (g.DG > 1 ? bd.cblks_q / (2 * bd.waves_c) : 1) * (g.nd + 1);
-  const bool single_owner = g.DG == 1 && bd.waves_c == 1 && bd.cblks_q == 2;   // direct writes, no buffer
-  auto size_red = [&]() {
-    bd.tap_group = 9;
-    bd.red_floats = single_owner ? 0 : bd.tap_group * red_per_tap;
-    if (bd.red_floats && bwd_data_lds_bytes(g, bd) > 80 * 1024) {
-      bd.tap_group = 3;
-      bd.red_floats = bd.tap_group * red_per_tap;
-    }
-  };
-  {
-    const int nbatch = g.nd == 2 ? 4 : 8, nquads = bd.ochunks / 4;
-    const bool straight = g.nd == 2 && g.G == 1 && nquads % nbatch == 0 && nquads / nbatch <= 2;
-    static const int bd_cl_env = getenv("MDCONV_BD_CL") ? atoi(getenv("MDCONV_BD_CL")) : -1;
-    bd.cl_drain = bd.cl;
-    size_red();
-    if (bd.cl && straight && (bd_cl_env == 0 || (bd_cl_env < 0 && bwd_data_lds_bytes(g, bd) > 80 * 1024))) {
-      bd.cl_drain = 0;
+    bd.cblks_q = (g.C + 64 * bd.waves_c - 1) / (64 * bd.waves_c) * (2 * bd.waves_c);
+    // GEMM-1 drain: channels-last (line-wide gathers through an LDS hand-over, mfma_bwd_data.hip)
+    // whenever the backward has the channels-last copy -- except for straight-line 2-D shapes whose
+    // LDS (grad_out tile + parked accumulators) would then allow only one workgroup per CU
+    // (C_in = 128, C_out = 256: 1.56 -> 1.70 ms).  MDCONV_BD_CL = 0 / 1 overrides.
+    // Reduction buffer [tap group][64-channel blocks to reduce][nd + 1][pixels of the tile]: groups of
+    // 3 taps instead of 9 where that keeps the kernel under 80 KB of LDS (two workgroups per CU).
+    const int red_per_tap = 128 * (g.DG > 1 ? bd.cblks_q / (2 * bd.waves_c) : 1) * (g.nd + 1);
+    const bool single_owner = g.DG == 1 && bd.waves_c == 1 && bd.cblks_q == 2;   // direct writes, no buffer
+    auto size_red = [&]() {
+      bd.tap_group = 9;
+      bd.red_floats = single_owner ? 0 : bd.tap_group * red_per_tap;
+      if (bd.red_floats && bwd_data_lds_bytes(g, bd) > 80 * 1024) {
+        bd.tap_group = 3;
+        bd.red_floats = bd.tap_group * red_per_tap;
+      }
+    };
+    {
+      const int nbatch = g.nd == 2 ? 4 : 8, nquads = bd.ochunks / 4;
+      const bool straight = g.nd == 2 && g.G == 1 && nquads % nbatch == 0 && nquads / nbatch <= 2;
+      static const int bd_cl_env = getenv("MDCONV_BD_CL") ? atoi(getenv("MDCONV_BD_CL")) : -1;
+      bd.cl_drain = bd.cl;
       size_red();
+      if (bd.cl && straight && (bd_cl_env == 0 || (bd_cl_env < 0 && bwd_data_lds_bytes(g, bd) > 80 * 1024))) {
+        bd.cl_drain = 0;
+        size_red();
+      }
     }
-  }
-  if (bwd_data_lds_bytes(g, bd) <= 150 * 1024 || bd.waves_c == 4) break;
-  bd.waves_c *= 2;
+    if (bwd_data_lds_bytes(g, bd) <= kBwdDataLdsCap || bd.waves_c == 4) break;
+    bd.waves_c *= 2;
   }
   const int nc = 1 << g.nd;
   size_t off = 0;
@@ -558,7 +558,7 @@ static bool native_supported(const Geom &g, int dtype, bool backward) {
     if (g.C < 16 || g.O < 16 || g.C % 8) return false;
     if (!(g.DG == 1 || g.Cdg == 64 || g.Cdg == 128 || g.Cdg % 256 == 0)) return false;
   }
-  if (backward && bwd_data_lds_bytes(g, bwd_dims(g)) > 150 * 1024) return false;   // grad_out tile lives in LDS
+  if (backward && bwd_data_lds_bytes(g, bwd_dims(g)) > kBwdDataLdsCap) return false;   // grad_out tile lives in LDS
   Plan p;
   return make_plan(g, dtype, backward, &p);   // one image must fit 32-bit buffer offsets
 }

@@ -155,6 +155,9 @@ size_t grad_bias_stage_bytes(const Geom &g);
 int grad_bias_f32(const Geom &g, const BwdDims &bd, const float *bias_part, float *stage, float *grad_bias,
                   hipStream_t stream);
 size_t bwd_data_lds_bytes(const Geom &g, const BwdDims &bd);   // dynamic LDS of GEMM-1
+// most dynamic LDS a GEMM-1 launch may ask for (of the CU's 160 KB): the bound bwd_dims() widens waves_c against,
+// mfma_supported() tests, and the launch raises every instance's MaxDynamicSharedMemorySize to, once
+constexpr size_t kBwdDataLdsCap = 150 * 1024;
 int mfma_bwd_data_f32(const Geom &g, const BwdDims &bd, const Tensors &t, const float *wq,
                       float *gcol, float *ga, float *bias_part, int *cnt, int *table,
                       const float *xt, hipStream_t stream);

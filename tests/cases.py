@@ -69,6 +69,9 @@ CASES = [
     _c("mfma_dcn3d_c32_o320_g1_lds", D3, 2, 32, 320, (4, 5, 6), 3, bias=False, tier="medium", seed=40),
     _c("mfma_dcn2d_c64_o640_lds", D2, 2, 64, 640, (9, 8), 3, in_step=1, tier="medium", seed=46),
     _c("mfma_mdcn3d_c128_dg2_o512_lds", M3, 1, 128, 512, (4, 5, 5), 3, dgroups=2, tier="medium", seed=47),
+    # ... the same idle-wave instances behind the deformable-group split (C_in / DG = 32 and 16 with a wide C_out, bias)
+    _c("mfma_mdcn3d_c64_dg2_o256_lds_bias", M3, 1, 64, 256, (5, 6, 5), 3, dgroups=2, tier="medium", seed=48),
+    _c("mfma_dcn3d_c32_dg2_o256_lds_bias", D3, 2, 32, 256, (4, 5, 6), 3, dgroups=2, in_step=1, tier="medium", seed=49),
     # kernel shapes / strides the MFMA kernels must also get right: 1x1, 5x5 stride 2 (25 taps =
     # three tap groups), rectangular, large dilation, anisotropic 3-D
     _c("mfma_mdcn2d_k1_c64_o32", M2, 2, 64, 32, (9, 11), 1, padding=0, tier="medium", seed=41),

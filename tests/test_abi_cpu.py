@@ -26,14 +26,17 @@ def test_library_exports_every_declared_symbol(capi):
     L = capi.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.mdconv_abi_version() == 1
+    assert L.mdconv_abi_version() == 2 == capi.ABI_VERSION
 
 
 def test_desc_struct_matches_header(capi):
     hdr = open(os.path.join(ROOT, "include", "mdconv.h")).read()
     body = hdr[hdr.index("typedef struct mdconv_desc {"):hdr.index("} mdconv_desc;")]
-    fields = re.findall(r"^\s*int\s+([a-z_]+)(?:\[3\])?;", body, re.M)
+    fields = re.findall(r"^\s*int\s+([a-z_]+)(?:\[[35]\])?;", body, re.M)
     assert fields == [f[0] for f in capi.MdconvDesc._fields_]
+    assert int(re.search(r"#define MDCONV_DESC_V2 (0x[0-9a-f]+)", hdr).group(1), 16) == capi.DESC_V2
+    # the v1 struct is a prefix of the v2 struct: a caller built against the v1 header passes 25 ints
+    assert fields.index("with_bias") == len(fields) - 5 and ctypes.sizeof(capi.MdconvDesc) == (25 + 8) * 4
 
 
 def _desc(capi, **kw):
@@ -71,6 +74,63 @@ def test_descriptor_validation_without_gpu(capi):
     big.in_sz = (ctypes.c_int * 3)(56, 56, 1)
     big.stride = (ctypes.c_int * 3)(2, 2, 1)
     assert L.mdconv_out_size(ctypes.byref(big), 1) == 28
+
+
+class _DescV1(ctypes.Structure):
+    """``struct mdconv_desc`` as the ABI v1 header declared it: ends at with_bias."""
+    _fields_ = [("ndim", ctypes.c_int), ("modulated", ctypes.c_int), ("dtype", ctypes.c_int),
+                ("batch", ctypes.c_int), ("c_in", ctypes.c_int), ("c_out", ctypes.c_int),
+                ("in_sz", ctypes.c_int * 3), ("k_sz", ctypes.c_int * 3), ("stride", ctypes.c_int * 3),
+                ("pad", ctypes.c_int * 3), ("dil", ctypes.c_int * 3), ("groups", ctypes.c_int),
+                ("dgroups", ctypes.c_int), ("in_step", ctypes.c_int), ("with_bias", ctypes.c_int)]
+
+
+def test_both_descriptor_versions_without_gpu(capi):
+    """ABI v1 descriptors (no MDCONV_DESC_V2 in ndim: the struct ends at with_bias, modes from the setters) and v2
+    descriptors (modes in the struct) are both accepted; a v2 descriptor is validated and overrides the setters."""
+    L = capi.lib()
+    null = ctypes.c_void_p(0)
+    # v1: a struct that really is only 25 ints long, placed at the END of a buffer so that a library reading a v2 tail
+    # would read the guard ints behind it
+    buf = (ctypes.c_int * (25 + 8))(*([0] * 25 + [0x5a5a5a5a] * 8))
+    v1 = _DescV1.from_buffer(buf)
+    v1.ndim, v1.modulated, v1.dtype, v1.batch, v1.c_in, v1.c_out = 2, 1, capi.F16, 2, 64, 64
+    v1.in_sz = (ctypes.c_int * 3)(8, 8, 1)
+    v1.k_sz = (ctypes.c_int * 3)(3, 3, 1)
+    v1.stride = (ctypes.c_int * 3)(1, 1, 1)
+    v1.pad = (ctypes.c_int * 3)(1, 1, 0)
+    v1.dil = (ctypes.c_int * 3)(1, 1, 1)
+    v1.groups, v1.dgroups, v1.in_step, v1.with_bias = 1, 1, 64, 0
+    assert L.mdconv_out_size(ctypes.byref(v1), 0) == 8
+    assert L.mdconv_workspace_bytes(ctypes.byref(v1), 1) > 0               # guard ints behind it: not read as modes
+    rc = L.mdconv_modulated_deform_conv2d_forward(ctypes.byref(v1), null, null, null, null, null, null, null,
+                                                  ctypes.c_size_t(0), null)
+    assert rc == -2 and "NULL" in capi.last_error()                         # passed validation, stopped at the pointers
+    # the v1 setters still exist and round-trip (they apply to v1 descriptors of the calling thread)
+    assert L.mdconv_set_accumulate(0) == 1 and L.mdconv_set_accumulate(1) == 0
+    assert L.mdconv_set_input_layout(1) == 0 and L.mdconv_set_input_layout(0) == 1
+    # v2: modes are validated ...
+    def fwd(d):
+        return L.mdconv_modulated_deform_conv2d_forward(ctypes.byref(d), null, null, null, null, null, null, null,
+                                                        ctypes.c_size_t(0), null)
+    v2 = lambda **kw: _desc(capi, ndim=2 | capi.DESC_V2, accumulate=1, **kw)
+    assert fwd(v2()) == -2
+    assert fwd(v2(path=5)) == -1 and "call mode" in capi.last_error()
+    assert fwd(v2(input_layout=3)) == -1
+    bad = v2()
+    bad.accumulate = 2
+    assert fwd(bad) == -1
+    res = v2()
+    res.reserved = (ctypes.c_int * 5)(0, 0, 1, 0, 0)
+    assert fwd(res) == -1 and "reserved" in capi.last_error()
+    # ... and decide per call: a forced direct path in the descriptor changes the plan of THIS descriptor only
+    # (fp16 backward: the shape-generic kernels need fp32 copies, the native 16-bit kernels a different workspace)
+    h = lambda **kw: _plan_desc(capi, 2, capi.F16, 2, 64, 64, (8, 8), **kw)
+    auto, direct = h(), h()
+    direct.path = capi.PATH_DIRECT
+    assert L.mdconv_workspace_bytes(ctypes.byref(auto), 1) != L.mdconv_workspace_bytes(ctypes.byref(direct), 1)
+    assert L.mdconv_input_layout_supported(ctypes.byref(auto), 1, 0) == 1
+    assert L.mdconv_input_layout_supported(ctypes.byref(direct), 1, 0) == 0
 
 
 def test_extension_module_surface_matches_reference():
@@ -122,7 +182,8 @@ def test_python_surface_and_cpu_behaviour():
 
 def _plan_desc(capi, nd, dtype, B, C, O, sz, G=1, DG=1, dil=1):
     d = capi.MdconvDesc()
-    d.ndim, d.modulated, d.dtype, d.batch, d.c_in, d.c_out = nd, 1, dtype, B, C, O
+    d.ndim, d.modulated, d.dtype, d.batch, d.c_in, d.c_out = nd | capi.DESC_V2, 1, dtype, B, C, O
+    d.accumulate = 1
     f = lambda v, x: tuple(v) + (x,) * (3 - nd)
     d.in_sz = (ctypes.c_int * 3)(*f(sz, 1))
     d.k_sz = (ctypes.c_int * 3)(*f((3,) * nd, 1))

@@ -271,3 +271,6 @@ def test_few_tile_many_stage_forward_runs_on_the_fp32_kernels(dtype):
     torch.cuda.synchronize()
     assert _capi.last_kernels() == "hp", _capi.last_kernels()
     assert_close("output (channels-last input)", out_cl.float(), want_out, TOL[dtype])
+    # the same shape takes two numeric routes depending only on the memory format of `input` (fp32 kernels on widened copies
+    # vs the native 16-bit kernel, INTEGRATION.md "Routing by memory format"): both within the 16-bit tolerance of each other
+    assert_close("output, contiguous vs channels-last input", out_cl.float(), out.float(), TOL[dtype])

@@ -28,8 +28,8 @@ def guarded(monkeypatch):
 
     def run_guarded(fn_name, d, backward, args_before_ws, input):
         L = _capi.lib()
-        cl = not input.is_contiguous() and M._is_channels_last(input)
-        with torch.cuda.device(input.device), _capi.channels_last_input(cl):
+        d.input_layout = int(not input.is_contiguous() and M._is_channels_last(input))
+        with torch.cuda.device(input.device):
             ws_bytes = L.mdconv_workspace_bytes(ctypes.byref(d), int(backward))
             big = torch.full((ws_bytes + 2 * PAD,), PATTERN, dtype=torch.uint8, device=input.device)
             stream = torch.cuda.current_stream().cuda_stream

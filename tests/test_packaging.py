@@ -25,7 +25,7 @@ for n in ("DeformConv2d", "ModulatedDeformConv2d", "DeformConv3d", "ModulatedDef
           "DeformConv2dPack", "ModulatedDeformConv2dPack", "deform_conv2d", "modulated_deform_conv2d"):
     assert hasattr(mdc, n), n
 from modulated_deform_conv_amd import _capi
-assert os.path.exists(_capi.LIB_PATH) and _capi.lib().mdconv_abi_version() == 1
+assert os.path.exists(_capi.LIB_PATH) and _capi.lib().mdconv_abi_version() == 2
 %s
 print("PACKAGING_OK")
 """

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: one line per run -- step / forward / backward time of a bench.py workload (HIP events over N eager
 steps) plus the in-library per-kernel events.  Environment knobs are read once per process, so every A/B leg is its
-own process:   MDCONV_BW_SPLITS=29 python tools/exp.py cfg2 [cfg2:4 ...] [--steps 20] [--label text]"""
+own process:   MDCONV_BWD_FORK=0 python tools/exp.py cfg2 [cfg2:4 ...] [--steps 20] [--label text]"""
 import os
 import sys
 
