@@ -251,11 +251,11 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary
-    (profiles/rNN*_pmc_summary.json, produced by tools/summarize_profile.py).  Counters cannot be
-    collected inside this process; the summary is stamped with the hash of the kernel sources it
-    was collected on and is REFUSED (None) when that differs from the sources being timed."""
+def _pmc_summary():
+    """(data, source note) of the newest committed rocprofv3 --pmc summary (profiles/rNN*_pmc_summary.json, produced by
+    tools/summarize_profile.py), or (None, note) when there is none or when it was collected on other kernel sources:
+    counters cannot be collected inside this process, so the summary is stamped with the hash of the sources it was
+    collected on and REFUSED when that differs from the sources being timed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
@@ -265,10 +265,62 @@ def measured_traffic(kernel):
     src = "%s (sources %s)" % (os.path.basename(files[-1]), stamp)
     if stamp != kernel_sources_sha16():
         return None, src + " -- stale: kernel sources changed since, traffic withheld"
+    return data, src
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` (headline workload) from the committed PMC summary."""
+    data, src = _pmc_summary()
+    if data is None:
+        return None, src
     for k, v in data.items():
-        if k.startswith(kernel):
+        if k.startswith(kernel) and isinstance(v, dict):
             return v["hbm_bytes_per_launch"], src
     return None, src
+
+
+def step_traffic(cfg, compulsory_bytes):
+    """Counter HBM traffic of one forward + backward step of `cfg` (all kernels; separate FETCH_SIZE / WRITE_SIZE passes of
+    tools/collect_profiles.sh over tools/bench_configs.py) against the compulsory bytes: the wasted-traffic ratio.  The read
+    side is quoted raw and doubled (MI355X_MICROARCH.md: FETCH_SIZE tallies the 128-byte requests of a stream at 64 B; for
+    gather-dominated kernels the raw figure is the closer one)."""
+    data, src = _pmc_summary()
+    ent = None if data is None else data.get("_steps", {}).get(cfg)
+    if ent is None:
+        return {"hbm_bytes_per_step": None, "source": src}
+    tot = 2 * ent["fetch_bytes_raw"] + ent["write_bytes"]
+    return {"hbm_bytes_per_step": tot, "fetch_bytes_raw": ent["fetch_bytes_raw"], "write_bytes": ent["write_bytes"],
+            "x_compulsory": round(tot / compulsory_bytes, 2),
+            "x_compulsory_fetch_raw": round((ent["fetch_bytes_raw"] + ent["write_bytes"]) / compulsory_bytes, 2),
+            "kernels": ent.get("kernels"), "source": src}
+
+
+def gather_path(wl, prof):
+    """The grad_input gather (`north_star`: "rocprof HBM GB/s (gather path)"): algorithmic bytes of the timed gather kernel
+    -- every grad_col row and every scatter-list entry read once, its result written once -- over its HIP-event time in
+    this run (it runs on the forked stream BESIDE GEMM-2 where the backward forks, so this is its rate under contention;
+    DESIGN.md section 4.2 quotes the alone-time)."""
+    name = next((k for k in prof if "col2im" in k), None)
+    if name is None or prof[name][1] <= 0:
+        return None
+    c = wl.cfg
+    nd, es = c["nd"], (4 if c["dtype"] == "f32" else 2)
+    pix, K, C, DG = wl.B * math.prod(c["sp"]), wl.K, c["C"], c["DG"]
+    hp = c["dtype"] != "f32"
+    cp = (C + 31) // 32 * 32 if hp else C
+    rows = pix * K * cp * es                                   # grad_col rows [b][tap][pix][c]
+    entry = 16 if nd == 2 else 32                              # bytes per list entry; fp32 2-D lists: one per corner PAIR
+    entries = pix * K * DG * entry * (2 if (nd == 2 and not hp) else 1)
+    two_pass = nd == 3 or hp
+    ns = 2 ** (nd - 1)
+    out = pix * ns * cp * es if two_pass else wl.B * C * math.prod(c["sp"]) * es   # per-anchor partial sums / grad_input
+    alg = rows + entries + out
+    ms = prof[name][1]
+    return {"kernel": name, "ms": round(ms, 4), "algorithmic_bytes": int(alg),
+            "achieved_GBs": round(alg / (ms * 1e-3) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "grad_col rows + list entries read once, %s written once; timed beside GEMM-2 where the backward forks"
+                    % ("per-anchor partial sums" if two_pass else "grad_input")}
 
 
 def cpu_baseline(iters=3):
@@ -330,7 +382,8 @@ def time_other_config(name, device, steps=5, warmup=2):
            "roofline": {"bound": c["bound"], "achieved": round(achieved, 2), "peak": c["peak"], "unit": unit,
                         "frac": round(achieved / c["peak"], 4), "scope": "whole step",
                         "compulsory_bytes": int(wl.bytes), "gemm_flop": 3 * wl.gemm_flop},
-           "kernels_ms": {k: round(v[1], 4) for k, v in prof.items()}}
+           "kernels_ms": {k: round(v[1], 4) for k, v in prof.items()},
+           "traffic": step_traffic(name, wl.bytes), "gather_path": gather_path(wl, prof)}
     del wl
     torch.cuda.empty_cache()
     return res
@@ -520,6 +573,9 @@ def main():
                          "achieved_GBs": round(comp / (ms_per_step * 1e-3) / 1e9, 1),
                          "peak_GBs": HBM_PEAK_GBS,
                          "frac": round(comp / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "traffic": ({"hbm_bytes_per_step": None, "source": "stub" if be.stub else "counters are collected on the B = 32 shard only"}
+                    if be.stub or wl.B != nominal_b else step_traffic("cfg2", comp)),
+        "gather_path": None if be.stub else gather_path(wl, prof),
     }
     if world == 1 and not distributed and not args.no_other_configs and not be.stub:
         del wl

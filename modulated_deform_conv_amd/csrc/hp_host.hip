@@ -174,8 +174,11 @@ HpDims hp_dims(const Geom &g) {
   if (ranges > hd.ntiles) ranges = hd.ntiles;
   hd.tiles_per_range = (hd.ntiles + ranges - 1) / ranges;
   hd.ranges = (hd.ntiles + hd.tiles_per_range - 1) / hd.tiles_per_range;
-  // GEMM-2 (dense, HBM-bound): 4 workgroups per CU in flight, at least 8 tiles per workgroup
-  int rw = num_cus() * 4 / g.K;
+  // GEMM-2 (dense, HBM-bound): 4 workgroups per CU in flight, at least 8 tiles per workgroup.  With 8 output blocks per
+  // wave (MB2 = 8: 128 accumulator registers, one resident workgroup per CU) one workgroup per CU: every range costs
+  // K x cblks x MB2 x 4 KB of fp32 partials written and read back (256 -> 256 channels at 56 x 56, B = 8: 98 ranges = 231 MB
+  // of partials beside 115 MB of column rows -- hp_gemm2 169 us + the reduction 50 us; 28 ranges: profiles/r06_experiments.md 2)
+  int rw = num_cus() * (hd.MB2 > 4 ? 1 : 4) / g.K;
   // (one dispatch round -- 3 resident per CU -- or 2 per CU: the cfg5 backward moves by +-0.03 ms, profiles/r05_experiments.md 8)
   if (rw < 1) rw = 1;
   if (rw > hd.max_ranges) hd.max_ranges = rw;
@@ -188,8 +191,11 @@ HpDims hp_dims(const Geom &g) {
 bool hp_supported(const Geom &g, int dtype, bool backward) {
   if (!hp_enabled()) return false;
   if (dtype != MDCONV_F16 && dtype != MDCONV_BF16) return false;
-  if (g.DG > 1 && g.Cdg % (backward ? 32 : 16)) return false;
+  if (g.DG > 1 && g.Cdg % 16) return false;
   const HpDims hd = hp_dims(g);
+  // backward with deformable groups of 16 / 48 / ... channels: the pixel-stationary kernel only (its lanes own 8 channels
+  // of one group each); the tap-stationary kernels reduce the coordinate sums per 32-channel block
+  if (backward && g.DG > 1 && g.Cdg % 32 && !use_bwd3(g, hd)) return false;
   if (backward) {
     if (hd.cblks > 8 || hd.MB2 > 8) return false;   // one workgroup covers all input channels
     if (g.in_sz[g.nd - 1] < 2) return false;        // pair-keyed scatter lists

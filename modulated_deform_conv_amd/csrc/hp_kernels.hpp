@@ -47,9 +47,9 @@ int hp_backward2_launch(const Geom &g, const HpDims &hd, int dtype, const Tensor
                         hipStream_t stream);
 
 // hp_bwd3.hip: pixel-stationary GEMM-1 + coordinate gradients + grad_col rows + column rows (GEMM-2 is
-// hp_gemm2.hip); one conv group, one deformable group, Cp a power of two
+// hp_gemm2.hip); one conv group, 1 / 2 / 4 deformable groups, Cp a power of two
 bool hp_bwd3_supported(const Geom &g, const HpDims &hd);
-size_t hp_bwd3_lds_bytes(const HpDims &hd);
+size_t hp_bwd3_lds_bytes(const Geom &g, const HpDims &hd);
 int hp_backward3_launch(const Geom &g, const HpDims &hd, int dtype, const Tensors &t, const void *xt,
                         const void *wpb, void *gcol, void *colbuf, int *cnt, hipStream_t stream);
 

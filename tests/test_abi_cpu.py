@@ -215,8 +215,10 @@ def test_workspace_plan_and_layout_query_without_gpu(capi):
     assert cl(cfg5, 0) == 1 and cl(cfg5, 1) == 1
     wide = _plan_desc(capi, 2, capi.BF16, 2, 512, 64, (8, 8))                # 16 channel blocks: forward only
     assert cl(wide, 0) == 1 and cl(wide, 1) == 0 and ws(wide, 1) > 0          # backward: fp32 copies on the fp32 kernels
-    dg16 = _plan_desc(capi, 2, capi.F16, 2, 64, 64, (8, 8), DG=4)            # deformable groups of 16 channels
-    assert cl(dg16, 0) == 1 and cl(dg16, 1) == 0 and ws(dg16, 1) > 0          # backward: shape-generic kernels on fp32 copies
+    dg16 = _plan_desc(capi, 2, capi.F16, 2, 64, 64, (8, 8), DG=4)            # 4 deformable groups of 16 channels
+    assert cl(dg16, 0) == 1 and cl(dg16, 1) == 1                              # round 6: the pixel-stationary backward takes them
+    dg6 = _plan_desc(capi, 2, capi.F16, 2, 96, 64, (8, 8), DG=6)              # 6 groups of 16 channels: forward only
+    assert cl(dg6, 0) == 1 and cl(dg6, 1) == 0 and ws(dg6, 1) > 0             # backward: fp32 kernels / shape-generic kernels on fp32 copies
     assert L.mdconv_input_layout_supported(ctypes.byref(cfg5), 0, 1) == 1    # NCHW always
     assert L.mdconv_input_layout_supported(ctypes.byref(cfg5), 7, 1) == 0
     assert capi.lib().mdconv_profile_name(9) == b""

@@ -6,6 +6,8 @@ run on the same 16-bit-rounded inputs.  Reference dtype dispatch: mdeformable_co
 Tolerance: 5e-3 (fp16) / 3e-2 (bf16) on both criteria of tests.util.assert_close -- the outputs
 themselves are rounded to 11 / 8 significant bits (measured worst case 1.9e-3 / 1.4e-2).
 """
+import os
+
 import pytest
 import torch
 
@@ -45,17 +47,33 @@ HP_CASES = [
     # pixel-stationary backward with 16 k-steps of output channels (C_out > 128: the register-heaviest variant)
     _c("hp_mdcn2d_c64_o256", M2, 1, 64, 256, (9, 8), 3, seed=121),
     _c("hp_dcn3d_c32_o200", D3, 1, 32, 200, (3, 5, 6), 3, bias=False, seed=122),
+    # W^T slab of one tap beyond 48 KB (round 6): the pixel-stationary backward reads its A fragments straight from global
+    # memory (hp_bwd3.hip, kWG) -- 256 x >= 128 and 128 x 256 channels, 2-D and 3-D, tiles that straddle images, 25 taps
+    _c("hp_dcn3d_c256_o128_wg", D3, 1, 256, 128, (3, 5, 6), 3, seed=123),
+    _c("hp_mdcn3d_c128_o256_wg", M3, 1, 128, 256, (4, 5, 5), 3, bias=False, seed=124),
+    _c("hp_mdcn2d_c128_o200_wg_b3", M2, 3, 128, 200, (7, 9), 3, seed=125),
+    _c("hp_dcn2d_c256_o256_wg_k5", D2, 2, 256, 256, (11, 10), 5, padding=2, seed=126),
+    # deformable groups on the pixel-stationary backward (round 6): a (tap, group) pair is a gather unit; groups of 16, 32, 64
+    # and 128 channels, 2 and 4 groups, with a staged W^T slab and with A fragments from global memory, 2-D and 3-D
+    _c("hp_mdcn2d_c64_dg4_o64", M2, 2, 64, 64, (9, 10), 3, dgroups=4, seed=127),
+    _c("hp_dcn2d_c32_dg2_o48", D2, 3, 32, 48, (7, 9), 3, dgroups=2, bias=False, seed=128),
+    _c("hp_dcn2d_c128_dg4_o96_s2", D2, 2, 128, 96, (12, 11), 3, stride=2, dgroups=4, seed=129),
+    _c("hp_mdcn2d_c256_dg4_o256", M2, 1, 256, 256, (8, 9), 3, dgroups=4, seed=130),
+    _c("hp_mdcn2d_c256_dg2_o128_dil2", M2, 2, 256, 128, (9, 8), 3, padding=2, dilation=2, dgroups=2, bias=False, seed=141),
+    _c("hp_mdcn3d_c64_dg2_o64", M3, 1, 64, 64, (4, 5, 6), 3, dgroups=2, seed=142),
+    _c("hp_dcn3d_c128_dg4_o64", D3, 1, 128, 64, (3, 6, 5), 3, dgroups=4, bias=False, seed=143),
+    _c("hp_mdcn3d_c64_dg4_o32_big_offsets", M3, 2, 64, 32, (4, 4, 5), 3, dgroups=4, seed=144, offset_scale=3.0),
 ]
 
 CASE_BY_HP = {c["name"]: c for c in HP_CASES}
 
 # 16-bit shapes the native kernels reject in at least one direction (hp_supported): more than 256
-# input channels / a block's output range above 256 in the backward, deformable groups of 16
-# channels.  fp16 AND bf16 must still work (fp32 copies through the fp32 kernels, else the
+# input channels / a block's output range above 256 in the backward, three deformable groups of 16
+# channels (the pixel-stationary backward takes 1, 2 or 4 groups).  fp16 AND bf16 must still work (fp32 copies through the fp32 kernels, else the
 # shape-generic kernels) -- ADVICE round 2: bf16 used to end in "unknown dtype 3".
 FALLBACK_CASES = [
     _c("fb_mdcn2d_c512_o64", M2, 1, 512, 64, (7, 6), 3, seed=131),
-    _c("fb_mdcn2d_c64_o64_dg4", M2, 2, 64, 64, (8, 7), 3, dgroups=4, seed=132),
+    _c("fb_mdcn2d_c48_o64_dg3", M2, 2, 48, 64, (8, 7), 3, dgroups=3, seed=132),
     _c("fb_dcn3d_c24_o8_g2", D3, 1, 24, 8, (4, 5, 4), 3, groups=2, bias=False, seed=133),
 ]
 
@@ -65,7 +83,10 @@ def _check(case, dtype, expect_hp=True, tol=None):
     t = make_inputs(case, dtype=dtype, device="cuda")
     out, grads, paths = run_product(case, t, "auto")
     torch.cuda.synchronize()
-    if expect_hp:
+    # (with the older backward kernels forced -- tests/test_gpu_hp_forced.py -- deformable groups of 16 channels have no
+    # native backward: only the pixel-stationary kernel takes them; the case still runs, on the fp32 kernels)
+    forced_old = os.environ.get("MDCONV_HP_BWD") in ("1", "2") and case["dgroups"] > 1 and (case["C"] // case["dgroups"]) % 32
+    if expect_hp and not forced_old:
         assert _capi.last_kernels() == "hp", (_capi.last_kernels(), paths)
     want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
     tol = tol or TOL[dtype]
@@ -84,6 +105,26 @@ def test_hp_fp16(case):
 @pytest.mark.parametrize("case", HP_CASES[::2], ids=lambda c: c["name"])
 def test_hp_bf16(case):
     _check(case, torch.bfloat16)
+
+
+@pytest.mark.parametrize("name", ["hp_mdcn2d_c256_o256", "hp_dcn3d_c256_o128_wg", "hp_mdcn3d_c128_o256_wg",
+                                  "hp_mdcn2d_c64_dg4_o64", "hp_mdcn2d_c256_dg4_o256", "hp_dcn3d_c128_dg4_o64"])
+def test_wide_backward_runs_on_the_pixel_stationary_kernel(name):
+    """256 -> 256 channels (the fp16 twin of the headline shape) used to run its backward on hp_bwd2, whose instance with 16
+    k-steps spills 744 bytes per lane; since round 6 hp_bwd3 takes it (A fragments from global memory) -- and shapes with 2 or
+    4 deformable groups, 16-channel groups included (those used to leave the 16-bit kernels)."""
+    from modulated_deform_conv_amd import _capi
+    case = CASE_BY_HP[name]
+    t = make_inputs(case, dtype=torch.float16, device="cuda")
+    _capi.profile_enable(True)
+    _capi.profile_reset()
+    try:
+        run_product(case, t, "auto")
+        torch.cuda.synchronize()
+        names = set(_capi.profile_read())
+    finally:
+        _capi.profile_enable(False)
+    assert "hp_bwd3_kernel" in names and "hp_gemm2_kernel" in names, names
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
