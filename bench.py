@@ -434,7 +434,20 @@ def main():
         if be.stub:
             dist.init_process_group(be.dist_backend)
         else:
-            dist.init_process_group(be.dist_backend, device_id=device)
+            # RCCL prints a version banner (ROCm version / Hostname / Librccl path) on STDOUT when the communicator is
+            # created, whatever NCCL_DEBUG_FILE says: stdout is pointed at stderr until the first collective has run, so
+            # that rank 0's stdout carries the ONE JSON line and nothing else
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(be.dist_backend, device_id=device)
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
 
     from modulated_deform_conv_amd import _capi
     from modulated_deform_conv_amd.distributed import FusedGradAllReduce, shard_bounds
@@ -453,32 +466,60 @@ def main():
         gw, gb = wl.backward()
         return out, gw, gb
 
-    graph = None
+    def compute_and_exchange():
+        out, gw, gb = compute()
+        # RCCL all-reduce of the fused [grad_weight || grad_bias] buffer on a side stream, released as soon as
+        # GEMM-2 / grad_bias are done (the library's weights-ready event), i.e. under the grad_input gather
+        reducer.reduce_overlapped(gw, gb)
+        return out, gw, gb
+
+    captured = False
+    graph, exchange = None, ("none (one rank)" if reducer is None else "eager: side stream under the grad_input gather")
     if use_graph:
-        # capture forward + backward once (plain kernel sequences on the capturing stream, scratch from
-        # the graph's private pool); the exchange stays outside the graph
+        # capture forward + backward once (plain kernel sequences on the capturing stream, scratch from the graph's
+        # private pool).  With peers the exchange is captured TOO: the communication stream joins the capture through
+        # the weights-ready event, so the replayed all-reduce runs under the gather exactly as in eager mode (until
+        # round 5 it was issued after the replay -- serial, on the 0.55 ms step of an 8-way strong-scaling shard).  If
+        # the collective cannot be captured on this stack, the step is re-captured without it and the exchange follows
+        # the replay; `exchange` in the JSON line says which.
+        # Capture mode "thread_local": the process group's watchdog thread polls the events of earlier collectives with
+        # hipEventQuery; under the default (global) capture mode such a call from ANY thread while this thread captures is an
+        # error that terminates the process (seen on the GPU box: "operation not permitted when stream is capturing" from
+        # ProcessGroupNCCL::Watchdog, profiles/r06_experiments.md 5).
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                compute()
+                (compute_and_exchange if reducer is not None else compute)()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static = compute()
+        if reducer is not None and os.environ.get("MDCONV_BENCH_EXCHANGE") != "after":
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    static = compute_and_exchange()
+                captured, exchange = True, "captured in the graph: side stream under the grad_input gather"
+            except Exception as e:   # noqa: BLE001 -- any capture failure: fall back, say so
+                sys.stderr.write("bench.py: the collective could not be captured (%s); exchange after the replay\n" % (e,))
+                torch.cuda.synchronize()
+                graph = None
+        if graph is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                static = compute()
+            if reducer is not None:
+                exchange = "after the graph replay (serial)"
 
     def step():
         if graph is not None:
             graph.replay()
-            if reducer is not None:
+            if reducer is not None and not captured:
                 reducer(static[1], static[2])      # after the replay, on the same stream
             return
-        _, gw, gb = compute()
         if reducer is not None:
-            # RCCL all-reduce of grad_weight || grad_bias on a side stream, released as soon as
-            # GEMM-2 / grad_bias are done, i.e. under the grad_input gather of the same backward
-            reducer.reduce_overlapped(gw, gb)
+            compute_and_exchange()
+        else:
+            compute()
 
     for _ in range(args.warmup):
         step()
@@ -558,7 +599,8 @@ def main():
         "sustained_ms_per_step": None if sustained is None else round(sustained[0], 4),
         "sustained_steps": None if sustained is None else sustained[1],
         "launch_mode": "hip graph replay" if graph is not None else "eager (one Python call per entry point)",
-        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+        "scaling": args.scaling, "exchange": exchange,
+        "exchange_mode": None if reducer is None else reducer.last_mode, "vs_baseline": None, "dtype": "f32",
         "data": "STUB -- host-only launcher test, no kernel ran, not a measurement" if be.stub else "synthetic",
         "config": {"workload": "%s, B=%d per GPU, forward+backward (BASELINE.json configs[1])" % (wl.cfg["what"], wl.B),
                    "global_batch": global_b, "parallelism": "dp%d batch-sharded" % world,

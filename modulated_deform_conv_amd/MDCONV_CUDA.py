@@ -17,6 +17,7 @@ import ctypes
 import torch
 
 from . import _capi
+from .distributed import fused_grad_buffers
 
 _DTYPES = {torch.float32: _capi.F32, torch.float16: _capi.F16, torch.float64: _capi.F64,
            torch.bfloat16: _capi.BF16}
@@ -232,8 +233,9 @@ def modulated_deform_conv2d_backward_cuda(input, weight, bias, offset, mask, gra
     grad_input = torch.empty_like(input, memory_format=torch.contiguous_format)
     grad_offset = torch.empty_like(offset)
     grad_mask = torch.empty_like(mask)
-    grad_weight = torch.empty_like(weight)
-    grad_bias = torch.empty_like(bias)
+    # grad_weight || grad_bias live in ONE flat buffer: the data-parallel exchange is then a single in-place all-reduce
+    # (distributed.py: fused_grad_buffers / FusedGradAllReduce)
+    grad_weight, grad_bias = fused_grad_buffers(weight, bias)
     _backward_checks(input, weight, offset, mask, grad_input, grad_weight, grad_bias, grad_offset,
                      grad_mask, grad_output, d, with_bias)
     d.accumulate = 0

@@ -35,17 +35,44 @@ def shard_batch(tensors, world_size=None, rank=None):
     return type(tensors)(cut(v) for v in tensors)
 
 
+def fused_grad_buffers(weight, bias=None):
+    """-> (grad_weight, grad_bias): views of ONE flat buffer [grad_weight || grad_bias] in the dtype of `weight`, so that
+    the data-parallel exchange is a single plain all-reduce of memory the backward wrote in place -- no staging copies, no
+    grouped launch ("a fused fp32 buffer").  The bindings allocate their weight gradients this way
+    (MDCONV_CUDA.modulated_deform_conv2d_backward_cuda, the autograd Functions, ops.py); `fused_view` finds the flat buffer
+    again from the two views.  `grad_bias` is a 0-element view when `bias` is None or empty."""
+    nb = 0 if bias is None else bias.numel()
+    flat = torch.empty(weight.numel() + nb, dtype=weight.dtype, device=weight.device)
+    return flat[:weight.numel()].view(weight.shape), flat[weight.numel():]
+
+
+def fused_view(grad_weight, grad_bias=None):
+    """The flat 1-D view over [grad_weight || grad_bias] when the two tensors are contiguous neighbours in one storage
+    (`fused_grad_buffers`), else None.  grad_bias may be None / empty (then: grad_weight alone, flattened)."""
+    if not grad_weight.is_contiguous():
+        return None
+    if grad_bias is None or grad_bias.numel() == 0:
+        return grad_weight.view(-1)
+    if (grad_bias.dtype != grad_weight.dtype or grad_bias.device != grad_weight.device or not grad_bias.is_contiguous()
+            or grad_bias.untyped_storage().data_ptr() != grad_weight.untyped_storage().data_ptr()
+            or grad_weight.data_ptr() + grad_weight.numel() * grad_weight.element_size() != grad_bias.data_ptr()):
+        return None
+    return torch.as_strided(grad_weight, (grad_weight.numel() + grad_bias.numel(),), (1,))
+
+
 class FusedGradAllReduce:
     """Sum grad_weight and grad_bias over the data-parallel group with ONE collective.
 
-    The flat fp32 buffer is allocated once and reused; gradients of other dtypes (fp16) are
-    reduced in fp32 and cast back, so the result matches a single-GPU fp32 accumulation."""
+    Gradients that live in one fused buffer (`fused_grad_buffers`: what the bindings of this package allocate) are reduced
+    IN PLACE by a single plain `all_reduce` (fp32 / fp64); 16-bit gradients are reduced in fp32 through one staging buffer
+    and cast back, so the result matches a single-GPU fp32 accumulation.  Tensors that are not neighbours are packed into
+    the staging buffer first.  Only public torch.distributed calls are used."""
 
     def __init__(self, group=None):
         self.group = group
         self._flat = None
         self._comm = None
-        self._grouped = None   # None = untried, True / False = the grouped in-place launch works / does not
+        self.last_mode = None   # "in-place" | "staged": how the last call ran (tests, bench.py)
 
     def _buffer(self, numel, device, dtype):
         dtype = torch.float64 if dtype == torch.float64 else torch.float32   # never below fp32
@@ -55,26 +82,13 @@ class FusedGradAllReduce:
         return self._flat
 
     def __call__(self, grad_weight, grad_bias=None, async_op=False):
-        grads = [g for g in (grad_weight, grad_bias) if g is not None and g.numel() > 0]
-        # RCCL, fp32 / fp64 gradients: both tensors in ONE grouped launch (ncclGroupStart / End), in place --
-        # no flat staging buffer, i.e. four copy kernels and their launches less per step (the exchange is
-        # 2.4 MB at cfg2: launch latency is all it costs)
-        if (not async_op and grads and self._grouped is not False
-                and all(g.is_cuda and g.is_contiguous() and g.dtype in (torch.float32, torch.float64) for g in grads)
-                and hasattr(dist, "_coalescing_manager") and dist.get_backend(self.group) == "nccl"):
-            # `_coalescing_manager` is a private torch API whose signature has changed between releases (2.0:
-            # (group, device, reqs)); a TypeError / AttributeError is raised on ENTERING the context, before any
-            # collective is issued, so falling back to the flat buffer below is safe -- and remembered
-            try:
-                cm = dist._coalescing_manager(group=self.group, device=grads[0].device, async_ops=False)
-            except (TypeError, AttributeError):
-                cm, self._grouped = None, False
-            if cm is not None:
-                with cm:
-                    for g in grads:
-                        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-                self._grouped = True
-                return None
+        fused = fused_view(grad_weight, grad_bias)
+        if fused is not None and fused.dtype in (torch.float32, torch.float64):
+            self.last_mode = "in-place"
+            work = dist.all_reduce(fused, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            return (work, lambda: None) if async_op else None
+        self.last_mode = "staged"
+        grads = [fused] if fused is not None else [g for g in (grad_weight, grad_bias) if g is not None and g.numel() > 0]
         flat = self._buffer(sum(g.numel() for g in grads), grads[0].device, grads[0].dtype)
         off = 0
         for g in grads:
@@ -114,9 +128,10 @@ class FusedGradAllReduce:
         _capi.stream_wait_weight_ready(self._comm, producer=main)
         with torch.cuda.stream(self._comm):
             self(grad_weight, grad_bias)
-        for g in (grad_weight, grad_bias):
-            if g is not None:
-                g.record_stream(self._comm)
+        if not torch.cuda.is_current_stream_capturing():   # (a captured step keeps its tensors alive itself)
+            for g in (grad_weight, grad_bias):
+                if g is not None:
+                    g.record_stream(self._comm)
         main.wait_stream(self._comm)
         return None
 

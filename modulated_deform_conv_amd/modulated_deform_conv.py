@@ -18,6 +18,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair, _triple
 
 from . import MDCONV_CUDA, _capi
+from .distributed import fused_grad_buffers
 
 __all__ = [
     "DeformConv2dFunction", "ModulatedDeformConv2dFunction", "DeformConv3dFunction",
@@ -108,7 +109,7 @@ def _make_function(nd, modulated, name):
             # are fresh, so the library is asked to write them instead (mdconv_set_accumulate)
             grad_input = torch.empty_like(input, memory_format=torch.contiguous_format)
             grad_offset = torch.empty_like(offset)
-            grad_weight, grad_bias = torch.empty_like(weight), torch.empty_like(bias)
+            grad_weight, grad_bias = fused_grad_buffers(weight, bias)   # one flat buffer: one in-place all-reduce (distributed.py)
             with _capi.overwrite_grads():
                 if modulated:
                     grad_mask = torch.empty_like(mask)

@@ -9,7 +9,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from modulated_deform_conv_amd.distributed import FusedGradAllReduce, shard_batch, shard_bounds
+from modulated_deform_conv_amd.distributed import (FusedGradAllReduce, fused_grad_buffers, fused_view, shard_batch,
+                                                   shard_bounds)
 from tests.cases import _c, make_inputs
 
 
@@ -92,3 +93,57 @@ def test_fused_allreduce_async_and_fp16():
         ret = dict(ret)
     assert torch.equal(ret["gw"], torch.full((3, 2, 3, 3), 3.0, dtype=torch.float16))
     assert torch.equal(ret["gb"], torch.full((3,), 1.5, dtype=torch.float16))
+
+
+def _worker_fused(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, b = torch.zeros(3, 2, 3, 3), torch.zeros(3)
+    red = FusedGradAllReduce()
+    modes = []
+    # (1) the layout the bindings allocate: one flat buffer, two views -> ONE in-place all-reduce, no staging
+    gw, gb = fused_grad_buffers(w, b)
+    gw.fill_(rank + 1.0); gb.fill_(10.0 * (rank + 1))
+    base_ptr = gw.data_ptr()
+    red(gw, gb)
+    modes.append((red.last_mode, red._flat is None, gw.data_ptr() == base_ptr))
+    # (2) no bias
+    gw2, gb2 = fused_grad_buffers(w, None)
+    gw2.fill_(rank + 1.0)
+    red.reduce_overlapped(gw2, gb2)
+    modes.append((red.last_mode, gb2.numel()))
+    # (3) two unrelated tensors: packed into the staging buffer
+    gw3, gb3 = torch.full_like(w, rank + 1.0), torch.full_like(b, 0.5)
+    red(gw3, gb3)
+    modes.append((red.last_mode,))
+    # (4) fp16 neighbours: reduced in fp32 through the staging buffer (one copy in, one out)
+    gw4, gb4 = fused_grad_buffers(w.half(), b.half())
+    gw4.fill_(rank + 1.0); gb4.fill_(0.25)
+    red(gw4, gb4)
+    modes.append((red.last_mode, red._flat.dtype))
+    if rank == 0:
+        ret["modes"] = modes
+        ret["vals"] = [gw.clone(), gb.clone(), gw2.clone(), gw3.clone(), gb3.clone(), gw4.clone(), gb4.clone()]
+    dist.destroy_process_group()
+
+
+def test_fused_buffer_is_reduced_in_place_by_one_plain_collective():
+    """the backward writes grad_weight || grad_bias into ONE buffer (fused_grad_buffers, what
+    MDCONV_CUDA / the autograd Functions allocate) and the exchange is a single `all_reduce` of it -- no staging copies,
+    no private torch.distributed API."""
+    assert fused_view(*fused_grad_buffers(torch.zeros(2, 3), torch.zeros(2))).numel() == 8
+    assert fused_view(torch.zeros(2, 3), torch.zeros(2)) is None
+    import inspect
+    from modulated_deform_conv_amd import distributed
+    assert "_coalescing_manager" not in inspect.getsource(distributed)
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_fused, args=(world, port, ret), nprocs=world, join=True)
+        ret = dict(ret)
+    m = ret["modes"]
+    assert m[0] == ("in-place", True, True) and m[1] == ("in-place", 0) and m[2] == ("staged",)
+    assert m[3] == ("staged", torch.float32)
+    gw, gb, gw2, gw3, gb3, gw4, gb4 = ret["vals"]
+    assert torch.all(gw == 3) and torch.all(gb == 30) and torch.all(gw2 == 3)
+    assert torch.all(gw3 == 3) and torch.all(gb3 == 1) and torch.all(gw4 == 3) and torch.all(gb4 == 0.5)
