@@ -220,6 +220,14 @@ def modulated_deform_conv2d_backward_cuda(input, weight, bias, offset, mask, gra
                                           dilation_w, group, deformable_group, in_step, with_bias):
     """reference mdeformable_conv.cu:361-366, 456; returns the tuple
     (grad_input, grad_offset, grad_mask, grad_weight, grad_bias) of new tensors."""
+    return _modulated2d_backward(True, input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h,
+                                 stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, in_step, with_bias)
+
+
+def _modulated2d_backward(fused, input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w,
+                          pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, in_step, with_bias):
+    """`fused`: grad_weight and grad_bias are views of ONE buffer (the data-parallel exchange reduces it in place);
+    False for torch.library operators, whose returns must not share storage (ops.py)."""
     _check_contig(input=input, weight=weight, bias=bias, offset=offset, mask=mask)
     grad_output = grad_output.contiguous()
     d = _desc(2, True, input, weight, (kernel_h, kernel_w), (stride_h, stride_w), (pad_h, pad_w),
@@ -235,7 +243,7 @@ def modulated_deform_conv2d_backward_cuda(input, weight, bias, offset, mask, gra
     grad_mask = torch.empty_like(mask)
     # grad_weight || grad_bias live in ONE flat buffer: the data-parallel exchange is then a single in-place all-reduce
     # (distributed.py: fused_grad_buffers / FusedGradAllReduce)
-    grad_weight, grad_bias = fused_grad_buffers(weight, bias)
+    grad_weight, grad_bias = fused_grad_buffers(weight, bias) if fused else (torch.empty_like(weight), torch.empty_like(bias))
     _backward_checks(input, weight, offset, mask, grad_input, grad_weight, grad_bias, grad_offset,
                      grad_mask, grad_output, d, with_bias)
     d.accumulate = 0

@@ -73,23 +73,31 @@ def build_variant(name, extra_flags):
     return lib
 
 
-def build_one_file_variant(name, src_basename, extra_flags):
-    """Developer aid: libmdconv_hip_<name>.so = the default objects with ONE source recompiled under extra
-    -D flags (ablation experiments that touch a single kernel file; seconds instead of a full rebuild)."""
+def build_files_variant(name, src_basenames, extra_flags):
+    """Developer aid: libmdconv_hip_<name>.so = the default objects with the named sources recompiled (in parallel) under
+    extra -D flags -- A/B builds that touch one kernel family; load it with MDCONV_LIB=<path>."""
     build()
     obj_dir = os.path.join(CSRC, "_obj_" + name)
     os.makedirs(obj_dir, exist_ok=True)
-    src = os.path.join(CSRC, src_basename)
-    obj = os.path.join(obj_dir, src_basename + ".o")
-    r = subprocess.run([_hipcc()] + FLAGS + FILE_FLAGS.get(src_basename, []) + list(extra_flags) + ["-c", src, "-o", obj],
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(r.stderr)
-    objs = [obj if os.path.basename(o) == src_basename + ".o" else o
-            for o in sorted(glob.glob(os.path.join(OBJ, "*.o")))]
+
+    def one(b):
+        obj = os.path.join(obj_dir, b + ".o")
+        r = subprocess.run([_hipcc()] + FLAGS + FILE_FLAGS.get(b, []) + list(extra_flags) + ["-c", os.path.join(CSRC, b), "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr)
+        return b + ".o", obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        swapped = dict(ex.map(one, src_basenames))
+    objs = [swapped.get(os.path.basename(o), o) for o in sorted(glob.glob(os.path.join(OBJ, "*.o")))]
     lib = os.path.join(HERE, "libmdconv_hip_%s.so" % name)
     subprocess.run([_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs, check=True)
     return lib
+
+
+def build_one_file_variant(name, src_basename, extra_flags):
+    return build_files_variant(name, [src_basename], extra_flags)
 
 
 def build(force=False, verbose=False):

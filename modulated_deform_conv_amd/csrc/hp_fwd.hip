@@ -237,8 +237,7 @@ static int launch_fwd_hp(const Geom &g, const HpDims &hd, const Tensors &t, cons
   switch (hd.MB) {
     case 1: HP_FWD(1); break;
     case 2: HP_FWD(2); break;
-    case 4: HP_FWD(4); break;
-    default: HP_FWD(8); break;
+    default: HP_FWD(4); break;   // (hp_dims: at most 4 output-channel blocks per row)
   }
 #undef HP_FWD
   return check_launch("hp_fwd");

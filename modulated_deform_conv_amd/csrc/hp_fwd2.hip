@@ -357,8 +357,7 @@ static int launch_fwd2_hp(const Geom &g, const HpDims &hd, const Tensors &t, con
   switch (hd.MB) {
     case 1: HP_FWD2(1); break;
     case 2: HP_FWD2(2); break;
-    case 4: HP_FWD2(4); break;
-    default: HP_FWD2(8); break;
+    default: HP_FWD2(4); break;   // (hp_dims: at most 4 output-channel blocks per row)
   }
 #undef HP_FWD2
 #undef HP_FWD2_

@@ -16,6 +16,8 @@
 
 namespace mdconv {
 
+int num_cus();   // mfma_bwd_data.hip
+
 namespace {
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -49,12 +51,33 @@ Geom chunk_geom(const Geom &g, int bc) {
 }
 
 // which backward kernel: MDCONV_HP_BWD = 1 -> hp_bwd (lane = pixel), 2 -> hp_bwd2 (fused, tap-stationary),
-// 3 (default) -> hp_bwd3 + hp_gemm2 where the shape qualifies, else as 2
+// 3 (default) -> hp_bwd3 + hp_gemm2 where the shape qualifies and is large enough to fill the chip (use_bwd3), else as 2;
+// 4 -> hp_bwd3 wherever it is supported (the test suite's way to reach every instance with small shapes)
 int bwd_version() {
   static const int v = getenv("MDCONV_HP_BWD") ? atoi(getenv("MDCONV_HP_BWD")) : 3;
   return v;
 }
-bool use_bwd3(const Geom &g, const HpDims &hd) { return bwd_version() >= 3 && hp_bwd3_supported(g, hd); }
+// hp_bwd2 instances that hold W^T[tap] and the grad_W[tap] accumulators without spilling (tools/kres.py hp_bwd2: 16 k-steps,
+// or 8 with the 8 + 2-wave workgroup, go to scratch) and shapes it takes at all (deformable groups of whole 32-channel blocks)
+static bool bwd2_takes(const Geom &g, const HpDims &hd) {
+  if (g.DG > 4 || (g.DG > 1 && g.Cdg % 32)) return false;
+  return hp_bwd2_lds_bytes(g, hd) <= 160 * 1024;
+}
+static bool bwd2_spills(const HpDims &hd) { return hd.nks >= 16 || (hd.waves >= 8 && hd.nks >= 8); }
+// Pixel-stationary (hp_bwd3 + hp_gemm2) or tap-stationary (hp_bwd2)?  hp_bwd3's workgroup walks ALL taps of its 128 pixels -- a
+// grid of at most one workgroup per CU is one long latency chain per CU -- while hp_bwd2's grid is (tap, pixel range): parallel
+// over the taps.  Measured crossover (profiles/r06_experiments.md 9: 27 shapes, both kernels): up to ~one 128-pixel tile per CU
+// hp_bwd2 wins by 5-40 % (3-D 128 -> 128 at 4 x 14 x 14, B = 4: 0.56 -> 0.37 ms per step), beyond ~1.5 per CU hp_bwd3 does.
+// The spilling instances of hp_bwd2 only while there are no more (tile, tap) pairs than CUs (3-D 256 -> 256 at 4 x 7 x 7, B = 4:
+// 7 tiles x 27 taps, 0.94 ms on hp_bwd3 against 0.57).
+bool use_bwd3(const Geom &g, const HpDims &hd) {
+  if (bwd_version() < 3 || !hp_bwd3_supported(g, hd)) return false;
+  if (bwd_version() == 3 && bwd2_takes(g, hd)) {
+    const long tiles = (g.N + 127) / 128;
+    if (bwd2_spills(hd) ? tiles * g.K <= num_cus() : tiles <= num_cus()) return false;
+  }
+  return true;
+}
 
 struct FwdLayout { size_t off_xt, off_w, off_tab, total; };
 struct BwdLayout { size_t off_xt, off_w, off_tab, off_gcol, off_col, off_part, off_gw32, off_cnt, off_rowptr, off_entries, off_sums, total; };
@@ -111,7 +134,6 @@ BwdLayout bwd_layout(const Geom &gc, const HpDims &hd, int dtype) {
 
 }  // namespace
 
-int num_cus();   // mfma_bwd_data.hip
 
 // workgroups per CU the fused backward kernel is sized for when it has 8 + 2 waves (C_in > 128)
 static int hp_wg_per_cu8() {
@@ -124,7 +146,13 @@ HpDims hp_dims(const Geom &g) {
   hd.cblks = hd.Cp / 32;
   hd.Op = (g.O + 31) / 32 * 32;
   hd.oblks = hd.Op / 32;
-  hd.MB = hd.oblks >= 5 ? 8 : (hd.oblks >= 3 ? 4 : hd.oblks);
+  // forward: output-channel blocks per workgroup row.  At most 4 (64 accumulator registers): the 8-block instance
+  // (128, one workgroup per CU) lost to two rows of 4 at EVERY batch size -- MDCN2d 256 -> 256 at 56 x 56 fp16: 477 -> 398 us at
+  // B = 32, 146 -> 123 at B = 8 -- although the rows gather the same corners twice (L2 hits).  Grids of fewer than half a
+  // workgroup per CU go down to single blocks: the kernel is one latency chain per workgroup there (B = 2: 96 -> 80 us,
+  // 14 x 14 at B = 16: 89 -> 65 us; profiles/r06_experiments.md 8).
+  hd.MB = hd.oblks >= 3 ? 4 : hd.oblks;
+  if (g.G == 1 && (long)((g.N + 127) / 128) * ((hd.oblks + hd.MB - 1) / hd.MB) * 2 < num_cus()) hd.MB = 1;
   if (g.G > 1) {
     // conv groups: a workgroup row only needs the output channels one 64-channel K stage can
     // reach (cfg3: 64 channels = 8 groups = 64 outputs), so rows are made that narrow -- more,

@@ -159,7 +159,11 @@ __device__ __forceinline__ void make_tap(const Geom &g, const int *o, const int 
     tc.low[a] = low;
     tc.wl[a] = vl ? (A)1 - d : (A)0;
     tc.wh[a] = vh_load ? d : (A)0;
-    tc.wha[a] = vh_atom ? d : (A)0;
+    // grad_input scatter weight of the high side.  The modulated 2-D file writes it as `(p + 1 - high)` (mdeformable_conv.cu:288,
+    // :292), which is `p - low` except that `p + 1` is rounded where it crosses a power of two -- visible on axes beyond
+    // 2^15 pixels, where an fp32 coordinate has an ulp of 2^-8 pixels; restated literally so that grad_input agrees with the
+    // reference there too (round 6; until then the kernels used `p - low` and differed by up to 2e-3 next to those columns)
+    tc.wha[a] = vh_atom ? (g.range_gate ? (pc + (A)1) - (A)(low + 1) : d) : (A)0;
     tc.sl[a] = vl ? (A)-1 : (A)0;
     tc.sh[a] = vh_load ? (A)1 : (A)0;
     const int lc = low < 0 ? 0 : (low > size - 1 ? size - 1 : low);

@@ -154,8 +154,8 @@ def deform_conv_backward(grad_output: torch.Tensor, input: torch.Tensor, offset:
                     bias is not None)
     fn = _entry(nd, mask is not None, True)
     if mask is not None and nd == 2:
-        gi, goff, gm, gw, gb = fn(input, weight, b, offset, mask, grad_output, *geo)
-        return gi, goff, gm, gw, gb
+        # (the export itself returns grad_weight / grad_bias as two views of one buffer; an operator's returns may not alias)
+        return MDCONV_CUDA._modulated2d_backward(False, input, weight, b, offset, mask, grad_output, *geo)
     gi, goff = torch.empty_like(input, memory_format=torch.contiguous_format), torch.empty_like(offset)
     gw, gb = torch.empty_like(weight), torch.empty_like(b)
     with _capi.overwrite_grads():   # fresh buffers: written, not added to

@@ -114,10 +114,12 @@ def forward(op, input, weight, bias, offset, mask=None, stride=1, padding=0, dil
 
 
 def backward(op, input, weight, bias, offset, mask, grad_output, stride=1, padding=0, dilation=1,
-             groups=1, dgroups=1, in_step=64, dtype=None):
+             groups=1, dgroups=1, in_step=64, dtype=None, intermediates=None):
     """Oracle backward from zero-initialised grads.
 
-    Returns dict(grad_input, grad_offset, grad_mask|None, grad_weight, grad_bias|None)."""
+    ``intermediates`` = torch.float16 / torch.bfloat16: the reference's `columns` / `grad_columns` buffers, which are
+    tensors of the input's type (mdeformable_conv.cu:396-397), are rounded to that type where the reference stores them;
+    everything else is computed in ``dtype``.  Returns dict(grad_input, grad_offset, grad_mask|None, grad_weight, grad_bias|None)."""
     dtype = dtype or (torch.float64 if input.dtype == torch.float64 else torch.float32)
     with_bias = bias is not None and bias.numel() > 0
     modulated = op in (MDCN2D, MDCN3D)
@@ -129,8 +131,12 @@ def backward(op, input, weight, bias, offset, mask, grad_output, stride=1, paddi
     gm = torch.zeros_like(m) if modulated else None
     gb = torch.zeros(d.c_out, dtype=dtype) if with_bias else None
     fn = lib().oracle_backward_f64 if dtype == torch.float64 else lib().oracle_backward_f32
-    rc = fn(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(o), _ptr(m), _ptr(go), _ptr(gx), _ptr(gw),
-            _ptr(gb), _ptr(goff), _ptr(gm))
+    lib().oracle_set_intermediate_rounding({None: 0, torch.float16: 1, torch.bfloat16: 2}[intermediates])
+    try:
+        rc = fn(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(o), _ptr(m), _ptr(go), _ptr(gx), _ptr(gw),
+                _ptr(gb), _ptr(goff), _ptr(gm))
+    finally:
+        lib().oracle_set_intermediate_rounding(0)
     if rc != 0:
         raise RuntimeError("oracle_backward: shape error")
     return dict(grad_input=gx, grad_offset=goff, grad_mask=gm, grad_weight=gw, grad_bias=gb)

@@ -58,6 +58,44 @@ static int oracle_check(const oracle_desc *d, int *nd, int *modulated, int *osz)
   return 0;
 }
 
+/* Storage type of the reference's two intermediate buffers.  `columns` and `grad_columns` are tensors of the INPUT's type
+ * (`at::zeros({...}, input.options())`, mdeformable_conv.cu:396-397; 3-D mdeformable_conv3d.cu:494-497), so with half
+ * tensors the reference rounds GEMM-1's result before its gradient kernel reads it (:418 -> :425) and the column values
+ * before GEMM-2 (:316 -> :436).  Mode 0 (default) keeps them in REAL; 1 / 2 round them to fp16 / bf16 (round to nearest
+ * even) at exactly those two points, everything else staying in REAL -- the numerics of the product's native 16-bit
+ * kernels, which keep coordinates and accumulators in fp32 (the reference's half COORDINATES are not restated, SURVEY.md
+ * section 7).  Used by the tests that pin where the 16-bit kernels' rounding sits. */
+static int oracle_inter_mode = 0;
+void oracle_set_intermediate_rounding(int mode) { oracle_inter_mode = (mode == 1 || mode == 2) ? mode : 0; }
+
+static float oracle_round_bf16(float v) {
+  unsigned u;
+  memcpy(&u, &v, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return v; /* NaN */
+  u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+  memcpy(&v, &u, 4);
+  return v;
+}
+static float oracle_round_f16(float v) {
+  /* round to nearest even onto the fp16 grid (normals, subnormals, overflow to inf), via scaling: exact in double */
+  if (!(v == v) || v == 0.0f) return v;
+  const double a = fabs((double)v);
+  if (a >= 65520.0) return v > 0 ? INFINITY : -INFINITY;
+  int e;
+  (void)frexp(a, &e);                      /* a = m * 2^e, m in [0.5, 1) */
+  int ulp_exp = e - 11;                    /* 11 significant bits */
+  if (ulp_exp < -24) ulp_exp = -24;        /* subnormal spacing 2^-24 */
+  const double q = ldexp(a, -ulp_exp);
+  const double r = nearbyint(q);           /* default rounding mode: to nearest even */
+  const double res = ldexp(r, ulp_exp);
+  return (float)(v > 0 ? res : -res);
+}
+static double oracle_round_inter(double v) {
+  if (oracle_inter_mode == 1) return (double)oracle_round_f16((float)v);
+  if (oracle_inter_mode == 2) return (double)oracle_round_bf16((float)v);
+  return v;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -70,6 +70,10 @@ int oracle_backward_f64(const oracle_desc *d, const double *input, const double 
                         double *grad_input, double *grad_weight, double *grad_bias,
                         double *grad_offset, double *grad_mask);
 
+/* Storage type of the reference's `columns` / `grad_columns` buffers (tensors of the input's type, mdeformable_conv.cu:396-397):
+ * 0 = as computed (default), 1 = rounded to fp16, 2 = to bf16 -- see mdconv_oracle.c.  Process-wide; tests set and reset it. */
+void oracle_set_intermediate_rounding(int mode);
+
 /* Threads the GEMM / per-image loops will use (OpenMP), for bench.py's cpu_baseline.cores. */
 int oracle_num_threads(void);
 

@@ -333,6 +333,10 @@ int FN(oracle_backward)(const oracle_desc *d, const REAL *input, const REAL *wei
     for (int g = 0; g < G; ++g)
       FN(gemm_tn)(rows_g, (int)ncol, Og, weight + (size_t)g * Og * rows_g,
                   gout + (size_t)g * Og * ncol, grad_columns + (size_t)g * rows_g * ncol);
+    if (oracle_inter_mode) { /* grad_columns is a tensor of the input's type (mdeformable_conv.cu:397, :418) */
+      const size_t ngc = (size_t)C * K * ncol;
+      for (size_t i = 0; i < ngc; ++i) grad_columns[i] = (REAL)oracle_round_inter((double)grad_columns[i]);
+    }
     FN(gradient_loop)(d, nd, modulated, step, osz, grad_columns,
                       input + (size_t)b * step * C * S_i,
                       offset + (size_t)b * step * DG * nd * K * S_o,
@@ -340,6 +344,10 @@ int FN(oracle_backward)(const oracle_desc *d, const REAL *input, const REAL *wei
                       grad_input + (size_t)b * step * C * S_i,
                       grad_offset + (size_t)b * step * DG * nd * K * S_o,
                       modulated ? grad_mask + (size_t)b * step * DG * K * S_o : NULL);
+    if (oracle_inter_mode) { /* ... and so is columns (:396, written at :316, read by the addmm_ at :436) */
+      const size_t ncl = (size_t)C * K * ncol;
+      for (size_t i = 0; i < ncl; ++i) columns[i] = (REAL)oracle_round_inter((double)columns[i]);
+    }
     for (int g = 0; g < G; ++g) {
       /* GEMM-2: grad_weight[g] += grad_output[b][g] @ columns[g]^T  (:436-439) */
       FN(gemm_nt_acc)(Og, rows_g, (int)ncol, gout + (size_t)g * Og * ncol,

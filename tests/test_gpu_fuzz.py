@@ -159,3 +159,35 @@ def test_wide_geometry_16bit(seed):
     for k, v in grads.items():
         if v is not None and want[k] is not None:
             assert_close(k, v.float(), want[k], tol)
+
+
+# The eleven per-element misses of the round-5 wide campaigns (profiles/r05_experiments.md 25, 30): 3-D shapes of 64-125 taps
+# (and one 3 x 2 input) whose output positions mostly sample padding, so that the criterion's rms is tiny; every one within
+# 2.3x of the campaign's tolerance, on grad_offset / grad_mask (one grad_weight).
+KNOWN_WIDE_MISSES = [(561, torch.bfloat16), (1360, torch.float16), (1374, torch.bfloat16), (1653, torch.bfloat16),
+                     (2542, torch.float16), (5808, torch.bfloat16), (10161, torch.bfloat16), (10788, torch.bfloat16),
+                     (30340, torch.float16), (30846, torch.bfloat16), (32169, torch.bfloat16)]
+
+
+@pytest.mark.parametrize("seed, dtype", KNOWN_WIDE_MISSES, ids=lambda v: str(v).replace("torch.", ""))
+def test_wide_16bit_misses_are_the_rounding_of_the_reference_s_own_half_buffers(seed, dtype):
+    """VERDICT r5 "what's weak" 2.  The native 16-bit kernels round grad_col between GEMM-1 and the coordinate sums, and the
+    column values before GEMM-2 -- exactly where the REFERENCE rounds with half tensors: its `grad_columns` and `columns`
+    buffers are tensors of the input's type (mdeformable_conv.cu:396-397; 3-D mdeformable_conv3d.cu:494-497).  Against the
+    oracle with those two buffers stored in the tensors' type (everything else fp32) the eleven shapes pass at the campaign's
+    STANDARD tolerance; against the all-fp32 oracle they stay within 2.5x of it, which pins the size of the deviation so
+    that a regression in these kernels shows up here."""
+    case = case_hp_wide(seed)
+    t = make_inputs(case, dtype=dtype, device="cuda")
+    out, grads, _ = run_product(case, t, "auto")
+    f32 = {k: (None if v is None else v.float()) for k, v in t.items()}
+    tol = 1e-2 if dtype == torch.float16 else 4e-2
+    want_out, want_ref = run_oracle(case, f32, torch.float32, intermediates=dtype)
+    assert_close("output", out.float(), want_out, tol)
+    for k, v in grads.items():
+        if v is not None and want_ref[k] is not None:
+            assert_close(k + " (oracle with the reference's 16-bit buffers)", v.float(), want_ref[k], tol)
+    _, want32 = run_oracle(case, f32, torch.float32)
+    for k, v in grads.items():
+        if v is not None and want32[k] is not None:
+            assert_close(k + " (all-fp32 oracle)", v.float(), want32[k], tol, 2.5 * tol)

@@ -107,24 +107,28 @@ def test_hp_bf16(case):
     _check(case, torch.bfloat16)
 
 
-@pytest.mark.parametrize("name", ["hp_mdcn2d_c256_o256", "hp_dcn3d_c256_o128_wg", "hp_mdcn3d_c128_o256_wg",
-                                  "hp_mdcn2d_c64_dg4_o64", "hp_mdcn2d_c256_dg4_o256", "hp_dcn3d_c128_dg4_o64"])
-def test_wide_backward_runs_on_the_pixel_stationary_kernel(name):
+def test_wide_backward_runs_on_the_pixel_stationary_kernel():
     """256 -> 256 channels (the fp16 twin of the headline shape) used to run its backward on hp_bwd2, whose instance with 16
-    k-steps spills 744 bytes per lane; since round 6 hp_bwd3 takes it (A fragments from global memory) -- and shapes with 2 or
-    4 deformable groups, 16-channel groups included (those used to leave the 16-bit kernels)."""
+    k-steps spills 744 bytes per lane; since round 6 hp_bwd3 takes it (A fragments from global memory) as soon as there is
+    more work than a few (tile, tap) pairs per CU -- with 4 deformable groups as well."""
     from modulated_deform_conv_amd import _capi
-    case = CASE_BY_HP[name]
-    t = make_inputs(case, dtype=torch.float16, device="cuda")
-    _capi.profile_enable(True)
-    _capi.profile_reset()
-    try:
-        run_product(case, t, "auto")
-        torch.cuda.synchronize()
-        names = set(_capi.profile_read())
-    finally:
-        _capi.profile_enable(False)
-    assert "hp_bwd3_kernel" in names and "hp_gemm2_kernel" in names, names
+    for dg in (1, 4):
+        case = _c("hp_wide_mdcn2d_c256_o256_28_dg%d" % dg, M2, 8, 256, 256, (28, 28), 3, dgroups=dg, seed=170 + dg)   # 49 tiles x 9 taps
+        t = make_inputs(case, dtype=torch.float16, device="cuda")
+        _capi.profile_enable(True)
+        _capi.profile_reset()
+        try:
+            out, grads, _ = run_product(case, t, "auto")
+            torch.cuda.synchronize()
+            names = set(_capi.profile_read())
+        finally:
+            _capi.profile_enable(False)
+        assert "hp_bwd3_kernel" in names and "hp_gemm2_kernel" in names, names
+        want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
+        assert_close("output", out.float(), want_out, TOL[torch.float16])
+        for key, g in grads.items():
+            if want[key] is not None:
+                assert_close(key, g.float(), want[key], TOL[torch.float16])
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
@@ -224,20 +228,25 @@ def test_non_finite_border_pixel_is_not_read():
     assert bad[:2, :2].all() and bad.sum().item() == 4
 
 
-def test_pixel_stationary_backward_is_what_runs():
-    """The shapes hp_bwd3 is written for (one conv group, one deformable group, C_in padded to a power of
-    two) take it by default -- seen through the profile slot names -- and MDCONV_HP_BWD=2 shapes keep the fused kernel."""
+def test_backward_kernel_choice_follows_shape_and_size():
+    """Which 16-bit backward kernel runs (seen through the profile slot names).  One conv group and 1 / 2 / 4 deformable groups:
+    the pixel-stationary hp_bwd3 once the grid fills the chip (more than one 128-pixel tile per CU) or where hp_bwd2 cannot
+    take the shape (16-channel groups) or would spill (16 k-steps with more than a few taps x tiles); the tap-stationary hp_bwd2
+    for small grids (parallel over the taps) and for conv groups; hp_bwd beyond four deformable groups."""
     from modulated_deform_conv_amd import _capi
     by = {c["name"]: c for c in HP_CASES}
-    for name, want in (("hp_mdcn3d_c128_o128_dil2", "hp_bwd3_kernel"), ("hp_mdcn2d_c64_o256", "hp_bwd3_kernel"),
-                       ("hp_mdcn2d_c256_o256_g32_dg4", "hp_bwd2_kernel"), ("hp_mdcn2d_c256_o64_dg8", "hp_bwd_kernel")):
-        t = make_inputs(by[name], dtype=torch.float16, device="cuda")
+    big = _c("hp_choice_mdcn2d_c64_o64_b12_56", M2, 12, 64, 64, (56, 56), 3, seed=160)        # 294 tiles of 128 pixels
+    wide = _c("hp_choice_mdcn2d_c64_o256_b4_56", M2, 4, 64, 256, (56, 56), 3, seed=161)       # 16 k-steps, 98 tiles x 9 taps
+    for case, want in ((big, "hp_bwd3_kernel"), (wide, "hp_bwd3_kernel"), (by["hp_mdcn2d_c64_dg4_o64"], "hp_bwd3_kernel"),
+                       (by["hp_mdcn3d_c128_o128_dil2"], "hp_bwd2_kernel"), (by["hp_mdcn2d_c64_o256"], "hp_bwd2_kernel"),
+                       (by["hp_mdcn2d_c256_o256_g32_dg4"], "hp_bwd2_kernel"), (by["hp_mdcn2d_c256_o64_dg8"], "hp_bwd_kernel")):
+        t = make_inputs(case, dtype=torch.float16, device="cuda")
         _capi.profile_enable(True)
         _capi.profile_reset()
-        run_product(by[name], t, "auto")
+        run_product(case, t, "auto")
         torch.cuda.synchronize()
         _capi.profile_enable(False)
-        assert want in _capi.profile_read(), (name, _capi.profile_read())
+        assert want in _capi.profile_read(), (case["name"], _capi.profile_read())
 
 
 def test_hp_accumulate_and_overwrite():

@@ -25,6 +25,18 @@ def test_parity_with_lane_per_pixel_16bit_kernels_forced():
     assert " passed" in r.stdout
 
 
+def test_parity_with_the_pixel_stationary_backward_forced():
+    """Small shapes take the tap-stationary hp_bwd2 by default since round 6 (hp_host.hip, use_bwd3: up to one 128-pixel tile
+    per CU); MDCONV_HP_BWD=4 keeps hp_bwd3 wherever it is supported, so that every instance the case list reaches -- staged
+    slabs, A fragments from global memory, 1 / 2 / 4 deformable groups of 16-128 channels -- is compared with the oracle."""
+    env = dict(os.environ, MDCONV_HP_BWD="4")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_hp.py", "tests/test_gpu_fuzz.py", "-m", "gpu", "-q", "-x",
+                        "-k", "test_hp_fp16 or test_hp_bf16 or accumulate_and_overwrite or 16bit_random_shapes"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 CHUNK_CODE = r"""
 import sys
 sys.path.insert(0, %r)

@@ -98,6 +98,10 @@ def test_op_takes_bf16_and_keeps_a_channels_last_input(dtype, nd, monkeypatch):
         orig = getattr(MDCONV_CUDA, name)
         monkeypatch.setattr(MDCONV_CUDA, name,
                             lambda inp, *a, _o=orig, _n=name: (seen.append((_n, inp.is_contiguous())), _o(inp, *a))[1])
+    if nd == 2:   # the operator calls the modulated 2-D backward through its non-fused form (returns must not share storage)
+        orig2 = MDCONV_CUDA._modulated2d_backward
+        monkeypatch.setattr(MDCONV_CUDA, "_modulated2d_backward",
+                            lambda fused, inp, *a: (seen.append(("bwd2d", inp.is_contiguous())), orig2(fused, inp, *a))[1])
     leaves = {n: (x_cl if n == "input" else t[n]).clone(memory_format=torch.preserve_format).requires_grad_(True)
               for n in ("input", "offset", "mask", "weight", "bias")}
     out = ops.deform_conv(leaves["input"], leaves["offset"], leaves["mask"], leaves["weight"], leaves["bias"], **conf)

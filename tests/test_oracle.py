@@ -176,3 +176,30 @@ def test_shape_errors(oracle_lib):
         oracle.forward(oracle.DCN2D, x, w, None, off, None, 1, 1, 1, 3, 1, 64)   # C % groups
     with pytest.raises(RuntimeError):
         oracle.forward(oracle.DCN2D, x, w, None, off, None, 1, 1, 1, 1, 1, 0)    # in_step = 0
+
+
+@pytest.mark.parametrize("inter", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_intermediate_storage_rounding_sits_where_the_reference_stores_them(oracle_lib, inter):
+    """`oracle.backward(..., intermediates=half)` rounds grad_columns after GEMM-1 and columns before GEMM-2 -- the two
+    buffers the reference allocates with input.options() (mdeformable_conv.cu:396-397) -- and nothing else.  1 x 1 kernel,
+    zero offsets, so that both are simple products: grad_mask = sum_c round(grad_col[c]) x[c], grad_weight[o, c] =
+    sum_n g[o, n] round(mask x[c, n]); the rounding itself is checked against torch's conversion (subnormals included)."""
+    g = torch.Generator().manual_seed(5)
+    B, C, O, H, W = 2, 5, 3, 4, 3
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(O, C, 1, 1, generator=g, dtype=torch.float64) * torch.tensor([1.0, 1e-3, 3e-6]).view(O, 1, 1, 1)
+    off = torch.zeros(B, 2, H, W, dtype=torch.float64)
+    m = torch.rand(B, 1, H, W, generator=g, dtype=torch.float64)
+    go = torch.randn(B, O, H, W, generator=g, dtype=torch.float64)
+    got = oracle.backward(oracle.MDCN2D, x, w, None, off, m, go, 1, 0, 1, 1, 1, 64, dtype=torch.float64, intermediates=inter)
+    rnd = lambda t: t.float().to(inter).double()
+    gcol = rnd(torch.einsum("oc,bohw->bchw", w[:, :, 0, 0], go))
+    want_gm = (gcol * x).sum(1, keepdim=True)
+    col = rnd(x * m)
+    want_gw = torch.einsum("bohw,bchw->oc", go, col)[:, :, None, None]
+    assert torch.allclose(got["grad_mask"], want_gm, rtol=1e-12, atol=1e-14)
+    assert torch.allclose(got["grad_weight"], want_gw, rtol=1e-12, atol=1e-14)
+    plain = oracle.backward(oracle.MDCN2D, x, w, None, off, m, go, 1, 0, 1, 1, 1, 64, dtype=torch.float64)
+    assert not torch.equal(plain["grad_mask"], got["grad_mask"])          # the mode does something ...
+    again = oracle.backward(oracle.MDCN2D, x, w, None, off, m, go, 1, 0, 1, 1, 1, 64, dtype=torch.float64)
+    assert torch.equal(plain["grad_mask"], again["grad_mask"])            # ... and is reset after the call

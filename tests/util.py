@@ -55,15 +55,16 @@ def run_product(case, t, path=None):
     return out, grads, paths
 
 
-def run_oracle(case, t, dtype):
-    """Oracle forward + backward on CPU copies of ``t`` computed in ``dtype``."""
+def run_oracle(case, t, dtype, intermediates=None):
+    """Oracle forward + backward on CPU copies of ``t`` computed in ``dtype``; ``intermediates`` = a 16-bit torch dtype
+    rounds the reference's columns / grad_columns buffers to it where the reference stores them (oracle.backward)."""
     args = (case["stride"], case["padding"], case["dilation"], case["groups"], case["dgroups"],
             case["in_step"])
     c = {k: (None if v is None else v.detach().cpu()) for k, v in t.items()}
     out = oracle.forward(case["op"], c["input"], c["weight"], c["bias"], c["offset"], c["mask"],
                          *args, dtype=dtype)
     g = oracle.backward(case["op"], c["input"], c["weight"], c["bias"], c["offset"], c["mask"],
-                        c["grad_output"], *args, dtype=dtype)
+                        c["grad_output"], *args, dtype=dtype, intermediates=intermediates)
     return out, g
 
 
