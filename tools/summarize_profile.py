@@ -71,7 +71,7 @@ def main(src, tag):
             pmc[k]["launches_" + counter] = len(v)
     summary = {}
     for k, v in pmc.items():
-        if not k.startswith(("mfma_", "col2im", "pack_", "csr_", "tap_", "grad_bias", "reduce_", "nchw_", "zero_")):
+        if not k.startswith(("mfma_", "col2im", "pack_", "csr_", "tap_", "grad_bias", "reduce_", "nchw_", "zero_", "bwd_prep", "fwd_tail")):
             continue
         f_raw = v.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024
         wr = v.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
@@ -82,6 +82,14 @@ def main(src, tag):
     stamp_file = os.path.join(src, "kernel_sources_sha16.txt")
     if os.path.exists(stamp_file):
         summary["_kernel_sources_sha16"] = open(stamp_file).read().strip()
+    # per-configuration step totals (tools/collect_steps.sh): bench.py's `traffic` fields of the headline and of other_configs
+    steps = {}
+    for cfg in ("cfg2", "cfg3", "cfg4", "cfg5"):
+        p = os.path.join(src, "steps_%s.json" % cfg)
+        if os.path.exists(p):
+            steps[cfg] = json.load(open(p))
+    if steps:
+        summary["_steps"] = steps
     json.dump(summary, open(os.path.join(out_dir, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     bench_json = None
     bj = os.path.join(src, "bench_full.json")
@@ -99,9 +107,15 @@ def main(src, tag):
             f.write("| %s | %s | %.1f | %s |\n" % (short(r["Name"])[:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
         f.write("\n## HBM traffic per launch (separate --pmc passes; KiB counters -> bytes; read side x2 per the gfx950 note)\n\n"
                 "| kernel | FETCH raw MB | FETCH x2 MB | WRITE MB | total MB |\n|---|---|---|---|---|\n")
-        for k, v in sorted(((k, v) for k, v in summary.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        for k, v in sorted(((k, v) for k, v in summary.items() if isinstance(v, dict) and not k.startswith("_")), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
             f.write("| %s | %.1f | %.1f | %.1f | %.1f |\n" % (k[:60], v["fetch_bytes_raw"] / 1e6, v["fetch_bytes_x2_gfx950"] / 1e6,
                                                           v["write_bytes"] / 1e6, v["hbm_bytes_per_launch"] / 1e6))
+        if steps:
+            f.write("\n## Counter traffic of one forward + backward step, all kernels (tools/collect_steps.sh over tools/bench_configs.py)\n\n"
+                    "| config | FETCH raw MB | FETCH x2 MB | WRITE MB | total (x2) MB |\n|---|---|---|---|---|\n")
+            for cfg, v in steps.items():
+                f.write("| %s | %.1f | %.1f | %.1f | %.1f |\n" % (cfg, v["fetch_bytes_raw"] / 1e6, 2 * v["fetch_bytes_raw"] / 1e6,
+                                                                 v["write_bytes"] / 1e6, (2 * v["fetch_bytes_raw"] + v["write_bytes"]) / 1e6))
         if bench_json:
             f.write("\n## bench.py line of the same build (un-profiled run)\n\n```\n%s\n```\n" % bench_json)
         for extra, title in (("bench_graph.json", "same build, `--graph` (step replayed from a HIP graph)"),
