@@ -5,7 +5,11 @@ extents (several 32-pixel tiles, ragged tile tails, batch tails), where the smal
           against the CPU oracle;    16-bit: native kernels against the oracle on the fp16 / bf16-rounded inputs.
   --wide: the geometry the case list and the other campaigns never reach -- kernel extents up to 7 (2-D) / 5 (3-D), i.e. 16 ... 125
           taps, strides and dilations up to 3, extents down to one output position, offsets up to 8 pixels.
-usage: python tools/fuzz_more.py [--seconds 420] [--first 100] [--wide]      prints one line per failure and a summary."""
+  --dg:   16-bit shapes of the pixel-stationary backward's round-6 domain: one conv group, 1 / 2 / 4 deformable groups of 16-128
+          channels on 32-256 input channels, up to 256 output channels (run it with MDCONV_HP_BWD=4 so that small shapes take hp_bwd3 too).
+16-bit results are compared with the oracle whose `columns` / `grad_columns` are stored in the tensors' type, as the reference's are
+(oracle.backward(intermediates=...), mdeformable_conv.cu:396-397): the rounding the kernels share with the reference is not an error.
+usage: python tools/fuzz_more.py [--seconds 420] [--first 100] [--wide | --dg]      prints one line per failure and a summary."""
 import os
 import random
 import sys
@@ -80,6 +84,27 @@ def case_hp(seed):
     size = size[:-1] + (max(size[-1], 2),)
     return _c("morehp%d" % seed, op, r.choice([1, 2, 3]), C, O, size, k, stride=stride, padding=pad, dilation=dil,
               groups=groups, dgroups=dg, in_step=64, bias=r.random() < 0.5, tier="medium", seed=8000 + seed,
+              offset_scale=r.choice([0.5, 1.0, 3.0]))
+
+
+def case_hp_dg(seed):
+    r = random.Random(55000 + seed)
+    nd = r.choice([2, 2, 3])
+    modulated = r.random() < 0.6
+    op = {(2, False): D2, (2, True): M2, (3, False): D3, (3, True): M3}[(nd, modulated)]
+    C = r.choice([32, 64, 128, 256])
+    dg = r.choice([d for d in (1, 2, 4) if C // d >= 16])
+    O = r.choice([8, 24, 32, 48, 64, 100, 128, 200, 256])
+    k = r.choice([1, 2, 3, 3]) if nd == 2 else r.choice([1, 2, 3])
+    stride = r.choice([1, 1, 2])
+    dil = r.choice([1, 1, 2])
+    pad = r.choice([0, 1, dil * (k - 1) // 2 + (1 if k > 1 else 0)])
+    lo = dil * (k - 1) + 1
+    hi = 28 if nd == 2 else 10
+    size = tuple(r.randint(max(lo, 3), hi) for _ in range(nd))
+    size = size[:-1] + (max(size[-1], 2),)
+    return _c("dghp%d" % seed, op, r.choice([1, 2, 3, 5]), C, O, size, k, stride=stride, padding=pad, dilation=dil,
+              groups=1, dgroups=dg, in_step=64, bias=r.random() < 0.5, tier="medium", seed=5500 + seed,
               offset_scale=r.choice([0.5, 1.0, 3.0]))
 
 
@@ -176,7 +201,7 @@ def main():
     if "--first" in a:
         first = int(a[a.index("--first") + 1])
     verbose = "--verbose" in a
-    gen32, gen16 = (case_f32_wide, case_hp_wide) if "--wide" in a else (case_f32, case_hp)
+    gen32, gen16 = (case_f32_wide, case_hp_wide) if "--wide" in a else ((case_f32, case_hp_dg) if "--dg" in a else (case_f32, case_hp))
     t0 = time.time()
     n = [0, 0, 0]
     bad = 0
@@ -228,7 +253,7 @@ def main():
         t = nan_margined(make_inputs(case, dtype=dtype, device="cuda"))
         out, grads, p = run_product(case, t, "auto")
         paths[("16", ) + tuple(p)] = paths.get(("16", ) + tuple(p), 0) + 1
-        want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
+        want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32, intermediates=dtype)
         tol = 1e-2 if dtype == torch.float16 else 4e-2
 
         def cmp16():
