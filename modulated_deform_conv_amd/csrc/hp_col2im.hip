@@ -389,7 +389,10 @@ constexpr int kRunM = 32;    // anchors per wave
 constexpr int kWtP = 40;     // pitch (16-bit elements) of the weight tile: 4 margin + 32 + up to 4 carry-out columns
 constexpr int kWtM = 4;      // left margin
 
-template <int ND, typename T, int NB>
+// HALF (round 6): lists of 16 channels (deformable groups of 16 channels) -- half a 32-column block: the rows fill columns
+// 0-15 of the row tile, columns 16-31 hold whatever the tile held (a column of the B operand reaches only its own column of
+// the product, and those are never stored).
+template <int ND, typename T, int NB, bool HALF = false>
 __global__ __launch_bounds__(256, NB <= 2 ? 4 : (NB == 4 ? 3 : 1)) void hp_col2im_sums_mfma_kernel(Geom g, HpDims hd, int S_e,
                                                                   const typename T::Raw *__restrict__ gcol,
                                                                   const int *__restrict__ rowptr,
@@ -402,10 +405,11 @@ __global__ __launch_bounds__(256, NB <= 2 ? 4 : (NB == 4 ? 3 : 1)) void hp_col2i
   // rounding per term (bf16 tensors keep the fp32-weight VALU kernel above)
   static_assert(ShortEntry<2, T>::value, "fp16 tensors only");
   constexpr int L = ND - 1, NS = 1 << L, AW = 32 / NS;
-  constexpr int CS = NB * 32;              // channels that share one list
+  static_assert(!HALF || NB == 1, "half blocks: one block");
+  constexpr int CS = HALF ? 16 : NB * 32;  // channels that share one list
   constexpr int PB = CS + 32;              // pitch of the row tile
   constexpr int LPR = CS / 8;              // lanes per grad_col row
-  constexpr int RPI = 64 / LPR;            // rows per wave-load (NB = 8: 2)
+  constexpr int RPI = 64 / LPR < 16 ? 64 / LPR : 16;   // rows per wave-load (NB = 8: 2; HALF: 16 rows on lanes 0-31)
   constexpr int NLD = 16 / RPI;            // wave-loads per step
   constexpr int RF = WIDE ? 8 : 16;        // rows of the window per flush pass (RF * CS * sizeof(Sum) = 32 CS bytes)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(256, NB <= 2 ? 4 : (NB == 4 ? 3 : 1)) void hp_col2i
       // ---- this step's 16 grad_col rows -> Rt ----
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
-        *reinterpret_cast<U4 *>(Rt + (i * RPI + r_row) * PB + r_piece * 8) = rows_cur[i];
+        if (!HALF || r_row < 16) *reinterpret_cast<U4 *>(Rt + (i * RPI + r_row) * PB + r_piece * 8) = rows_cur[i];
       // ---- 16 entries x 32 NB channels into the window's accumulators ----
       // (compiler fences: the tiles are written and read through differently typed pointers)
       asm volatile("" ::: "memory");
@@ -535,6 +539,7 @@ __global__ __launch_bounds__(256, NB <= 2 ? 4 : (NB == 4 ? 3 : 1)) void hp_col2i
           // accumulator r of this lane = row (r & 3) + 8 (r >> 2) + 4 kh, column nb * 32 + pl
           if ((8 * (r >> 2)) / RF == ps) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kh - ps * RF;
+            if (HALF && pl >= CS) continue;
             if constexpr (WIDE) Ft[row * CS + nb * 32 + pl] = acc[nb][r];
             else T::stf(reinterpret_cast<Raw *>(Ft) + row * CS + nb * 32 + pl, acc[nb][r]);
           }
@@ -543,6 +548,7 @@ __global__ __launch_bounds__(256, NB <= 2 ? 4 : (NB == 4 ? 3 : 1)) void hp_col2i
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int q = lane + 64 * i;                          // 16-byte piece of the pass: 2 CS pieces in all
+        if (HALF && q >= 2 * CS) continue;
         const int row = (q * 16 / (int)sizeof(Sum)) / CS + ps * RF;
         const U4 v = reinterpret_cast<const U4 *>(Ft)[q];
         if (w0 + row / NS < S_e)
@@ -692,7 +698,13 @@ static int launch_col2im2(const Geom &g, const HpDims &hd, const Tensors &t, con
   const int nb = cseg / 32;
   bool on_mfma = false;
   if constexpr (ShortEntry<2, T>::value) {   // (F16: the trait names the tensor type)
-    if (cseg % 32 == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8)) {
+    if (cseg == 16) {
+      const int runs = g.B * g.DG * ((S_e + kRunM - 1) / kRunM);
+      const size_t lds = (size_t)4 * (16 * kWtP * 2 + 16 * (cseg + 32) * 2);
+      hipLaunchKernelGGL((hp_col2im_sums_mfma_kernel<ND, T, 1, true>), dim3((runs + 3) / 4), dim3(256), lds, stream, g, hd,
+                         S_e, (const Raw *)gcol, rowptr, (const int4 *)entries, (typename SumStore<T>::type *)sums);
+      on_mfma = true;
+    } else if (cseg % 32 == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8)) {
       const int runs = g.B * g.DG * ((S_e + kRunM - 1) / kRunM);
       const size_t lds = (size_t)4 * (16 * kWtP * 2 + 16 * (cseg + 32) * 2);
 #define HP_C2M(NBV)                                                                              \
