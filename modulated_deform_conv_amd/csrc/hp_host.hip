@@ -68,13 +68,17 @@ static bool bwd2_spills(const HpDims &hd) { return hd.nks >= 16 || (hd.waves >= 
 // grid of at most one workgroup per CU is one long latency chain per CU -- while hp_bwd2's grid is (tap, pixel range): parallel
 // over the taps.  Measured crossover (profiles/r06_experiments.md 9: 27 shapes, both kernels): up to ~one 128-pixel tile per CU
 // hp_bwd2 wins by 5-40 % (3-D 128 -> 128 at 4 x 14 x 14, B = 4: 0.56 -> 0.37 ms per step), beyond ~1.5 per CU hp_bwd3 does.
-// The spilling instances of hp_bwd2 only while there are no more (tile, tap) pairs than CUs (3-D 256 -> 256 at 4 x 7 x 7, B = 4:
-// 7 tiles x 27 taps, 0.94 ms on hp_bwd3 against 0.57).
+// The spilling instances of hp_bwd2 cross over earlier, at a tile count that falls with the channel count (hp_bwd2's time per
+// (tile, tap) pair grows with C_in x C_out, hp_bwd3's latency chain per tap hardly) and is about twice as high in 3-D: measured
+// on 21 shapes with 16 k-steps (profiles/r06_experiments.md 16) at 13-25 tiles for 2-D 256 -> 256, 25-49 for 3-D 256 -> 256,
+// 25-98 for 2-D 128 -> 256, beyond 49 for 3-D 128 -> 256 -- tiles <= CUs x 16 (36 in 3-D) / C_in.  (Round 6 first shipped
+// "(tile, tap) pairs <= CUs" from one data point: 3-D 256 -> 256 at 4 x 14 x 14, B = 2 went to hp_bwd3 at 0.88 ms against 0.56.)
 bool use_bwd3(const Geom &g, const HpDims &hd) {
   if (bwd_version() < 3 || !hp_bwd3_supported(g, hd)) return false;
   if (bwd_version() == 3 && bwd2_takes(g, hd)) {
     const long tiles = (g.N + 127) / 128;
-    if (bwd2_spills(hd) ? tiles * g.K <= num_cus() : tiles <= num_cus()) return false;
+    const long limit = bwd2_spills(hd) ? (long)num_cus() * (g.nd == 3 ? 36 : 16) / hd.Cp : num_cus();
+    if (tiles <= limit) return false;
   }
   return true;
 }
@@ -241,8 +245,11 @@ bool hp_supported(const Geom &g, int dtype, bool backward) {
 bool hp_forward_preferred(const Geom &g, int dtype) {
   static const bool forced = getenv("MDCONV_HP_FWD") != nullptr;
   if (forced) return true;
-  const HpDims hd = hp_dims(g);
-  const long wgs = (long)((g.N + 127) / 128) * hd.oranges;
+  // counted in rows of 8 output blocks whatever rows hp_dims picks: single-block rows (small grids, MB = 1) multiply the
+  // workgroups, not the work one of them finishes per unit time (2048 -> 512 at 7 x 7, B = 8: 64 single-block workgroups
+  // 675 us, the fp32 route 277 us; profiles/r06_experiments.md 15)
+  const int oblks = (g.O + 31) / 32;
+  const long wgs = (long)((g.N + 127) / 128) * ((oblks + 7) / 8);
   const long stages = (long)g.K * ((g.C + 63) / 64);
   if (wgs > 16 || stages < 64) return true;
   return !mfma_supported(g, dtype, false);

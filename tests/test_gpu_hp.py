@@ -237,7 +237,11 @@ def test_backward_kernel_choice_follows_shape_and_size():
     by = {c["name"]: c for c in HP_CASES}
     big = _c("hp_choice_mdcn2d_c64_o64_b12_56", M2, 12, 64, 64, (56, 56), 3, seed=160)        # 294 tiles of 128 pixels
     wide = _c("hp_choice_mdcn2d_c64_o256_b4_56", M2, 4, 64, 256, (56, 56), 3, seed=161)       # 16 k-steps, 98 tiles x 9 taps
+    # 16 k-steps in 3-D, 256 channels: hp_bwd2 (spilling instance) up to ~36 tiles, hp_bwd3 beyond (experiment log 16)
+    few3 = _c("hp_choice_mdcn3d_c256_o256_b2", M3, 2, 256, 256, (4, 14, 14), 3, seed=162)       # 13 tiles x 27 taps
+    many3 = _c("hp_choice_mdcn3d_c256_o256_b8", M3, 8, 256, 256, (4, 14, 14), 3, seed=163)      # 49 tiles
     for case, want in ((big, "hp_bwd3_kernel"), (wide, "hp_bwd3_kernel"), (by["hp_mdcn2d_c64_dg4_o64"], "hp_bwd3_kernel"),
+                       (few3, "hp_bwd2_kernel"), (many3, "hp_bwd3_kernel"),
                        (by["hp_mdcn3d_c128_o128_dil2"], "hp_bwd2_kernel"), (by["hp_mdcn2d_c64_o256"], "hp_bwd2_kernel"),
                        (by["hp_mdcn2d_c256_o256_g32_dg4"], "hp_bwd2_kernel"), (by["hp_mdcn2d_c256_o64_dg8"], "hp_bwd_kernel")):
         t = make_inputs(case, dtype=torch.float16, device="cuda")
@@ -324,3 +328,29 @@ def test_few_tile_many_stage_forward_runs_on_the_fp32_kernels(dtype):
     # the same shape takes two numeric routes depending only on the memory format of `input` (fp32 kernels on widened copies
     # vs the native 16-bit kernel, INTEGRATION.md "Routing by memory format"): both within the 16-bit tolerance of each other
     assert_close("output, contiguous vs channels-last input", out_cl.float(), out.float(), TOL[dtype])
+
+
+@pytest.mark.parametrize("name,op,B,C,O,sz", [
+    ("hp_route_c512_o512_7x7", M2, 8, 512, 512, (7, 7)),        # 4 tiles x 16 output blocks: 64 single-block rows, still "few"
+    ("hp_route_c1024_o256_7x7_dg4", M2, 4, 1024, 256, (7, 7)),
+    ("hp_route_3d_c256_o256_4x7x7", M3, 4, 256, 256, (4, 7, 7)),
+], ids=lambda v: v if isinstance(v, str) else None)
+def test_few_tile_rule_counts_work_not_workgroups(name, op, B, C, O, sz):
+    """The few-tile rule must not depend on how many output blocks a workgroup row of the native forward holds: small grids
+    run single-block rows (round 6), which multiplied the workgroup count the rule looked at and sent these forwards back to
+    one-latency-chain native workgroups (2.4x slower than round 5; profiles/r06_experiments.md 15)."""
+    from modulated_deform_conv_amd import MDCONV_CUDA as M, _capi
+    nd = len(sz)
+    case = _c(name, op, B, C, O, sz, 3, dgroups=4 if name.endswith("dg4") else 1, seed=137)
+    t = make_inputs(case, dtype=torch.float16, device="cuda")
+    geo = (3,) * nd + (1,) * (3 * nd) + (1, case["dgroups"], 64, True)
+    x, w, b, off, m = t["input"], t["weight"], t["bias"], t["offset"], t["mask"]
+    if nd == 2:
+        out = M.modulated_deform_conv2d_forward_cuda(x, w, b, off, m, *geo)
+    else:
+        out = torch.empty_like(t["grad_output"])
+        M.modulated_deform_conv3d_forward_cuda(x, w, b, off, m, out, *geo)
+    torch.cuda.synchronize()
+    assert _capi.last_kernels() == "f32", _capi.last_kernels()
+    want_out, _ = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)
+    assert_close("output", out.float(), want_out, TOL[torch.float16])

@@ -20,9 +20,29 @@ for (C, O, sz, B) in [(32, 32, (8, 28, 28), 2), (64, 64, (8, 28, 28), 2), (64, 1
     SHAPES.append(("mdcn3d", M3, B, C, O, sz, 1))
     SHAPES.append(("dcn3d", D3, B, C, O, sz, 1))
 
+# --more: a second set (other batch sizes, DCN without mask, bf16 is chosen with --dtypes) used to compare two trees on one box
+MORE = []
+for (C, O, hw, B) in [(256, 256, 28, 8), (128, 128, 56, 8), (256, 256, 56, 2), (256, 256, 56, 32), (64, 64, 112, 4), (512, 512, 28, 4),
+                      (256, 512, 28, 8), (512, 256, 14, 16), (128, 256, 28, 16), (256, 256, 7, 32), (32, 32, 112, 8),
+                      (256, 256, 14, 64), (1024, 256, 14, 4), (256, 1024, 14, 4)]:
+    for dg in (1, 2):
+        MORE.append(("mdcn2d", M2, B, C, O, (hw, hw), dg))
+    MORE.append(("dcn2d", D2, B, C, O, (hw, hw), 1))
+for (C, O, sz, B) in [(64, 64, (16, 28, 28), 2), (128, 128, (8, 14, 14), 4), (32, 64, (16, 56, 56), 1), (128, 128, (8, 28, 28), 2),
+                      (256, 256, (4, 14, 14), 2), (64, 64, (4, 56, 56), 2)]:
+    MORE.append(("mdcn3d", M3, B, C, O, sz, 1))
+    MORE.append(("dcn3d", D3, B, C, O, sz, 1))
+
 
 def main():
-    for dtype in (torch.float32, torch.float16):
+    global SHAPES
+    dts = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+    dtypes = (torch.float32, torch.float16)
+    if "--more" in sys.argv:
+        SHAPES = MORE
+    if "--dtypes" in sys.argv:
+        dtypes = tuple(dts[x] for x in sys.argv[sys.argv.index("--dtypes") + 1].split(","))
+    for dtype in dtypes:
         for name, op, B, C, O, sz, dg in SHAPES:
             case = _c(name, op, B, C, O, sz, 3, dgroups=dg, tier="medium", seed=1)
             t = make_inputs(case, dtype=dtype, device="cuda")
