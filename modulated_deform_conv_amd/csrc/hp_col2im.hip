@@ -614,9 +614,9 @@ __global__ __launch_bounds__(256) void hp_col2im_combine_kernel(Geom g, HpDims h
     __syncthreads();
     for (int x = threadIdx.x; x < CW * QT; x += 256) {
       const int cl = x / QT, ql = x - cl * QT;
-      const int c = c0 + cl, q = q0 + ql;
-      if (c < g.C && q < g.S_i) {
-        Raw *dst = grad_input + ((int64_t)b * g.C + c) * g.S_i + q;
+      const int c = caller_channel(g, c0 + cl), q = q0 + ql;
+      if (c >= 0 && q < g.S_i) {
+        Raw *dst = grad_input + ((int64_t)b * caller_channels(g) + c) * g.S_i + q;
         const float v = (float)tile[cl * TP + ql];
         T::stf(dst, g.acc_data ? T::ldf(dst) + v : v);
       }

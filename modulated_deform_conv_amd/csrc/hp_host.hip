@@ -220,7 +220,39 @@ HpDims hp_dims(const Geom &g) {
   return hd;
 }
 
+// Deformable groups the native kernels cannot tile -- 24 / 48 / 80 ... channels: not whole pairs of 8-channel lanes, or not the
+// power-of-two lane count the pixel-stationary backward gives a group -- run GROUP-PADDED (round 6): the kernels see groups of
+// 32 / 64 / 128 channels (Geom::cm_pad), the four layout passes that touch the caller's C-indexed tensors (channels-last input
+// copy, weight packing, grad_weight reduction, grad_input stencil) map the channels (caller_channel, mdconv_common.hpp), and
+// the padding channels carry zero input and zero weights.  Up to 2x the channel work instead of DG single-group fp32 slices
+// through workspace copies (fp16 96 -> 96 at 40 x 40, 4 groups: 1.11 -> 0.33 ms; profiles/r06_experiments.md 17).  Not for a
+// channels-last input (read in place, C wide) nor with the one-pass gather (MDCONV_HP_C2I=1 writes grad_input itself).
+static bool group_padded(const Geom &g, Geom *gv) {
+  if (g.cm_pad || g.G != 1 || g.DG == 1 || g.in_cl || !use_col2im2()) return false;
+  int cdp = (g.DG == 2 || g.DG == 4) ? pow2_ceil(g.Cdg) : (g.Cdg + 31) / 32 * 32;
+  if (cdp < 16) cdp = 16;
+  if (cdp == g.Cdg) return false;
+  *gv = g;
+  gv->C = gv->Cg = g.DG * cdp;
+  gv->Cdg = cdp;
+  gv->cm_pad = cdp;
+  gv->cm_real = g.Cdg;
+  gv->C_caller = g.C;
+  return true;
+}
+
+static bool hp_supported_as(const Geom &g, int dtype, bool backward);
+// the geometry the native kernels run for `g`: g itself or its group-padded form
+static bool hp_plan_geom(const Geom &g, int dtype, bool backward, Geom *ge) {
+  if (hp_supported_as(g, dtype, backward)) { *ge = g; return true; }
+  return group_padded(g, ge) && hp_supported_as(*ge, dtype, backward);
+}
 bool hp_supported(const Geom &g, int dtype, bool backward) {
+  Geom ge;
+  return hp_plan_geom(g, dtype, backward, &ge);
+}
+
+static bool hp_supported_as(const Geom &g, int dtype, bool backward) {
   if (!hp_enabled()) return false;
   if (dtype != MDCONV_F16 && dtype != MDCONV_BF16) return false;
   if (g.DG > 1 && g.Cdg % 16) return false;
@@ -242,9 +274,11 @@ bool hp_supported(const Geom &g, int dtype, bool backward) {
 // through fp32 copies (the route of every 16-bit shape the native kernels do not take: fp32 accumulation, one rounding of
 // the output).  Not with a channels-last input (only the native kernels read it in place), not when MDCONV_HP_FWD selects a
 // kernel explicitly (the forced-path tests).
-bool hp_forward_preferred(const Geom &g, int dtype) {
+bool hp_forward_preferred(const Geom &gcall, int dtype) {
   static const bool forced = getenv("MDCONV_HP_FWD") != nullptr;
   if (forced) return true;
+  Geom g;
+  if (!hp_plan_geom(gcall, dtype, false, &g)) return false;
   // counted in rows of 8 output blocks whatever rows hp_dims picks: single-block rows (small grids, MB = 1) multiply the
   // workgroups, not the work one of them finishes per unit time (2048 -> 512 at 7 x 7, B = 8: 64 single-block workgroups
   // 675 us, the fp32 route 277 us; profiles/r06_experiments.md 15)
@@ -252,10 +286,12 @@ bool hp_forward_preferred(const Geom &g, int dtype) {
   const long wgs = (long)((g.N + 127) / 128) * ((oblks + 7) / 8);
   const long stages = (long)g.K * ((g.C + 63) / 64);
   if (wgs > 16 || stages < 64) return true;
-  return !mfma_supported(g, dtype, false);
+  return !mfma_supported(gcall, dtype, false);
 }
 
-size_t hp_workspace_bytes(const Geom &g, int dtype, bool backward) {
+size_t hp_workspace_bytes(const Geom &gcall, int dtype, bool backward) {
+  Geom g;
+  if (!hp_plan_geom(gcall, dtype, backward, &g)) return 0;
   HpDims hd = hp_dims(g);
   const int bc = chunk_batch(g, hd, backward);
   if (bc <= 0) return 0;
@@ -278,7 +314,9 @@ static bool fwd2_rows_align(const Geom &g, const HpDims &hd) {
   return true;
 }
 
-int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+int hp_forward(const Geom &gcall, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  Geom g;   // the caller's geometry or its group-padded form
+  if (!hp_plan_geom(gcall, dtype, false, &g)) { set_error("hp_forward: no plan"); return MDCONV_EUNSUPPORTED; }
   const int Bc = chunk_batch(g, hp_dims(g), false);
   if (Bc <= 0) { set_error("hp_forward: no plan"); return MDCONV_EUNSUPPORTED; }
   const Geom g0 = chunk_geom(g, Bc);
@@ -294,7 +332,7 @@ int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t
     const Geom gc = chunk_geom(g, bc);
     const HpDims hd = hp_dims(gc);
     Tensors tc = t;
-    tc.input = (const char *)t.input + (size_t)b0 * g.C * g.S_i * 2;
+    tc.input = (const char *)t.input + (size_t)b0 * caller_channels(g) * g.S_i * 2;
     tc.offset = (const char *)t.offset + (size_t)b0 * nc_off * g.S_o * 2;
     tc.mask = t.mask ? (const char *)t.mask + (size_t)b0 * nc_m * g.S_o * 2 : nullptr;
     tc.output = (char *)t.output + (size_t)b0 * g.O * g.S_o * 2;
@@ -317,7 +355,9 @@ int hp_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t
   return MDCONV_OK;
 }
 
-int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+int hp_backward(const Geom &gcall, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
+  Geom g;   // the caller's geometry or its group-padded form
+  if (!hp_plan_geom(gcall, dtype, true, &g)) { set_error("hp_backward: no plan"); return MDCONV_EUNSUPPORTED; }
   const int Bc = chunk_batch(g, hp_dims(g), true);
   if (Bc <= 0) { set_error("hp_backward: no plan"); return MDCONV_EUNSUPPORTED; }
   const Geom g0 = chunk_geom(g, Bc);
@@ -335,11 +375,11 @@ int hp_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_
     const bool multi = Bc < g.B, first = b0 == 0, last = b0 + bc >= g.B;
     const HpDims hd = hp_dims(gc);
     Tensors tc = t;
-    tc.input = (const char *)t.input + (size_t)b0 * g.C * g.S_i * 2;
+    tc.input = (const char *)t.input + (size_t)b0 * caller_channels(g) * g.S_i * 2;
     tc.offset = (const char *)t.offset + (size_t)b0 * nc_off * g.S_o * 2;
     tc.mask = t.mask ? (const char *)t.mask + (size_t)b0 * nc_m * g.S_o * 2 : nullptr;
     tc.grad_output = (const char *)t.grad_output + (size_t)b0 * g.O * g.S_o * 2;
-    tc.grad_input = (char *)t.grad_input + (size_t)b0 * g.C * g.S_i * 2;
+    tc.grad_input = (char *)t.grad_input + (size_t)b0 * caller_channels(g) * g.S_i * 2;
     tc.grad_offset = (char *)t.grad_offset + (size_t)b0 * nc_off * g.S_o * 2;
     tc.grad_mask = t.grad_mask ? (char *)t.grad_mask + (size_t)b0 * nc_m * g.S_o * 2 : nullptr;
     int *cnt = (int *)(base + L.off_cnt), *rowptr = (int *)(base + L.off_rowptr);

@@ -11,9 +11,9 @@ int grid_for(int64_t total, int cap = 8192) {
   return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
-// xt[b][q][Cp] = x[b][c][q] (0 for c >= C): 64 x 64 tiles through LDS, 16-byte stores.
+// xt[b][q][Cp] = x[b][caller_channel(c)][q] (0 for padding channels): 64 x 64 tiles through LDS, 16-byte stores.
 // Element type agnostic (moves 16-bit words).
-__global__ __launch_bounds__(256) void hp_nchw_to_nhwc_kernel(int C, int Cp, int S,
+__global__ __launch_bounds__(256) void hp_nchw_to_nhwc_kernel(Geom g, int Cp, int S,
                                                               const unsigned short *__restrict__ x,
                                                               unsigned short *__restrict__ xt) {
   __shared__ unsigned short t[64][66];
@@ -21,8 +21,8 @@ __global__ __launch_bounds__(256) void hp_nchw_to_nhwc_kernel(int C, int Cp, int
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll 4
   for (int r = ty; r < 64; r += 4) {
-    const int c = c0 + r, q = q0 + tx;
-    t[r][tx] = (c < C && q < S) ? x[((size_t)b * C + c) * S + q] : (unsigned short)0;
+    const int c = caller_channel(g, c0 + r), q = q0 + tx;
+    t[r][tx] = (c >= 0 && q < S) ? x[((size_t)b * caller_channels(g) + c) * S + q] : (unsigned short)0;
   }
   __syncthreads();
   for (int item = threadIdx.x; item < 64 * 8; item += 256) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void hp_nchw_to_nhwc_kernel(int C, int Cp, int
 // The same copy with 8-byte loads along q (4 pixels of one channel per lane: 4 load instructions per thread instead
 // of 16 two-byte ones) for S a multiple of 4 and an 8-byte aligned source; LDS tile and the 16-byte stores as above.
 // Picked for rows of 512 bytes (cfg3, C = 256), where the transposing-read variant below loses.
-__global__ __launch_bounds__(256) void hp_nchw_to_nhwc_q4_kernel(int C, int Cp, int S,
+__global__ __launch_bounds__(256) void hp_nchw_to_nhwc_q4_kernel(Geom g, int Cp, int S,
                                                                  const unsigned short *__restrict__ x,
                                                                  unsigned short *__restrict__ xt) {
   __shared__ __attribute__((aligned(8))) unsigned short t[64][68];   // pitch 136 B: 8-byte aligned rows
@@ -50,9 +50,9 @@ __global__ __launch_bounds__(256) void hp_nchw_to_nhwc_q4_kernel(int C, int Cp, 
   const int u = threadIdx.x & 15, r0 = threadIdx.x >> 4;   // pixel quad, channel row (16 rows per pass)
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
-    const int r = r0 + 16 * pass, c = c0 + r, q = q0 + u * 4;
+    const int r = r0 + 16 * pass, c = caller_channel(g, c0 + r), q = q0 + u * 4;
     uint2 v = make_uint2(0u, 0u);
-    if (c < C && q < S) v = *reinterpret_cast<const uint2 *>(x + ((size_t)b * C + c) * S + q);   // S % 4 == 0: whole quad inside
+    if (c >= 0 && q < S) v = *reinterpret_cast<const uint2 *>(x + ((size_t)b * caller_channels(g) + c) * S + q);   // S % 4 == 0: whole quad inside
     *reinterpret_cast<uint2 *>(&t[r][u * 4]) = v;
   }
   __syncthreads();
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void hp_nchw_to_nhwc_q4_kernel(int C, int Cp, 
 // land one pixel row apart, which pays for rows of 256 bytes (cfg5, C = 128: 95 -> 61 us) and not for rows of 512
 // (cfg3, C = 256: 36 -> 41 us) -- the launcher picks by row length.  (Vector loads with the two-byte LDS reads of
 // the kernel above: 16-byte aligned rows put a pixel's 8 channel octets in one bank, 49 / 82 us.)
-__global__ __launch_bounds__(256) void hp_nchw_to_nhwc_vec_kernel(int C, int Cp, int S,
+__global__ __launch_bounds__(256) void hp_nchw_to_nhwc_vec_kernel(Geom g, int Cp, int S,
                                                                   const unsigned short *__restrict__ x,
                                                                   unsigned short *__restrict__ xt) {
   constexpr int P = 80;
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void hp_nchw_to_nhwc_vec_kernel(int C, int Cp,
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (tid >> 3) + 32 * i, u = tid & 7;
-    const int c = c0 + row, q = q0 + u * 8;
+    const int c = caller_channel(g, c0 + row), q = q0 + u * 8;
     U4 v = {0, 0, 0, 0};
-    if (c < C && q < S) v = *reinterpret_cast<const U4 *>(x + ((size_t)b * C + c) * S + q);
+    if (c >= 0 && q < S) v = *reinterpret_cast<const U4 *>(x + ((size_t)b * caller_channels(g) + c) * S + q);
     *reinterpret_cast<U4 *>(t + row * P + u * 8) = v;
   }
   __syncthreads();
@@ -108,6 +108,21 @@ __global__ __launch_bounds__(256) void hp_nchw_to_nhwc_vec_kernel(int C, int Cp,
 // forward A operand: wpf[tap][chunk][oblk][lane][8] = W[o = oblk*32 + (lane&31)]
 //                                                      [c = chunk*16 + 8*(lane>>5) + j][tap]
 // dense block-diagonal over conv groups (0 where o and c belong to different groups, or padding).
+// element index of weight[o][c][tap] in the caller's [O][C_in / groups][K] tensor for channel c of the kernels' rows; -1 where
+// o and c belong to different conv groups or either is padding (the group-padded layout has one conv group)
+__device__ __forceinline__ int64_t hp_weight_index(const Geom &g, int o, int c, int tap) {
+  if (o >= g.O) return -1;
+  if (g.cm_pad) {
+    const int cc = caller_channel(g, c);
+    return cc < 0 ? -1 : ((int64_t)o * g.C_caller + cc) * g.K + tap;
+  }
+  return (c < g.C && o / g.Og == c / g.Cg) ? ((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap : -1;
+}
+__device__ __forceinline__ unsigned short hp_weight_or_zero(const Geom &g, const unsigned short *__restrict__ w, int o, int c,
+                                                           int tap) {
+  const int64_t e = hp_weight_index(g, o, c, tap);
+  return e < 0 ? (unsigned short)0 : w[e];
+}
 __device__ void hp_ctab_fill(const Geom &g, const HpDims &hd, int2 *__restrict__ ctab);
 __device__ __forceinline__ int4 hp_btab_entry(const Geom &g, int cblk);
 // (block 0 also writes the chunk table the forward kernel reads: one launch less than a table kernel of its own)
@@ -129,8 +144,7 @@ __global__ __launch_bounds__(256) void hp_pack_fwd_kernel(Geom g, HpDims hd,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = cb + j;
-      e[j] = (o < g.O && c < g.C && o / g.Og == c / g.Cg)
-                 ? w[((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap] : (unsigned short)0;
+      e[j] = hp_weight_or_zero(g, w, o, c, tap);
     }
     U4 v;
     v.x = e[0] | ((u32)e[1] << 16); v.y = e[2] | ((u32)e[3] << 16);
@@ -191,8 +205,7 @@ __global__ __launch_bounds__(256) void hp_pack_bwd_kernel(Geom g, HpDims hd, int
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int o = ob + j;
-      e[j] = (o < g.O && c < g.C && o / g.Og == c / g.Cg)
-                 ? w[((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap] : (unsigned short)0;
+      e[j] = hp_weight_or_zero(g, w, o, c, tap);
     }
     U4 v;
     v.x = e[0] | ((u32)e[1] << 16); v.y = e[2] | ((u32)e[3] << 16);
@@ -226,7 +239,8 @@ __global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, in
     const int tap = (int)(r / hd.cblks);
     const int o = btab[cblk].x + ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
     const int c = cblk * 32 + (lane & 31);
-    if (o < g.O && c < g.C && o / g.Og == c / g.Cg) {
+    const int64_t e = hp_weight_index(g, o, c, tap);
+    if (e >= 0) {
       const int64_t per_range = (int64_t)hd.cblks * hd.MB2 * 1024;
       const float *p = part + ((int64_t)tap * ranges) * per_range + ((int64_t)cblk * hd.MB2 + ob) * 1024 +
                        lane * 16 + reg;
@@ -238,7 +252,6 @@ __global__ __launch_bounds__(256) void hp_reduce_gw_kernel(Geom g, HpDims hd, in
         s += (a0 + a1) + (a2 + a3);
       }
       for (; k < ranges; ++k) s += p[(int64_t)k * per_range];
-      const int64_t e = ((int64_t)o * g.Cg + (c % g.Cg)) * g.K + tap;
       // calls cut into batch chunks keep the running sum in fp32 (gw32) and round ONCE, after the
       // last chunk, like the single-chunk path
       if (gw32) {
@@ -300,13 +313,13 @@ __global__ __launch_bounds__(kBiasThreads) void hp_grad_bias_kernel(Geom g, cons
 int hp_nchw_to_nhwc(const Geom &g, const HpDims &hd, const void *x, void *xt, hipStream_t stream) {
   const dim3 grid((g.S_i + 63) / 64, (hd.Cp + 63) / 64, g.B);
   if (hd.Cp <= 128 && g.S_i % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-    hipLaunchKernelGGL(hp_nchw_to_nhwc_vec_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
+    hipLaunchKernelGGL(hp_nchw_to_nhwc_vec_kernel, grid, dim3(256), 0, stream, g, hd.Cp, g.S_i,
                        (const unsigned short *)x, (unsigned short *)xt);
   else if (g.S_i % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
-    hipLaunchKernelGGL(hp_nchw_to_nhwc_q4_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
+    hipLaunchKernelGGL(hp_nchw_to_nhwc_q4_kernel, grid, dim3(256), 0, stream, g, hd.Cp, g.S_i,
                        (const unsigned short *)x, (unsigned short *)xt);
   else
-    hipLaunchKernelGGL(hp_nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, g.C, hd.Cp, g.S_i,
+    hipLaunchKernelGGL(hp_nchw_to_nhwc_kernel, grid, dim3(256), 0, stream, g, hd.Cp, g.S_i,
                        (const unsigned short *)x, (unsigned short *)xt);
   return check_launch("hp_nchw_to_nhwc");
 }

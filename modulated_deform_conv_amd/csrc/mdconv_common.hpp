@@ -35,7 +35,19 @@ struct Geom {
   int acc_data, acc_w;
   // 1 = `input` is channels-last [B, spatial..., C] (mdconv_set_input_layout; 16-bit kernels only)
   int in_cl;
+  // Group-padded channel layout of the native 16-bit path (hp_host.hip, hp_group_padded): deformable groups of 24 / 48 / ...
+  // channels run as groups of cm_pad = 32 / 64 / ... channels -- C, Cg, Cdg above describe the PADDED problem the kernels see,
+  // channel c of it is channel (c / cm_pad) * cm_real + c % cm_pad of the caller's C_caller-channel tensors when
+  // c % cm_pad < cm_real, else padding (zero input, zero weights).  cm_pad == 0: channels are the caller's.
+  int cm_pad, cm_real, C_caller;
 };
+// channel of the caller's input / weight / grad_input / grad_weight behind channel c of the kernels' rows; -1 = padding
+__host__ __device__ __forceinline__ int caller_channel(const Geom &g, int c) {
+  if (g.cm_pad == 0) return c < g.C ? c : -1;
+  const int q = c / g.cm_pad, r = c - q * g.cm_pad;
+  return (q < g.DG && r < g.cm_real) ? q * g.cm_real + r : -1;
+}
+__host__ __device__ __forceinline__ int caller_channels(const Geom &g) { return g.cm_pad ? g.C_caller : g.C; }
 
 template <typename T> struct Acc { using type = float; };
 template <> struct Acc<double> { using type = double; };

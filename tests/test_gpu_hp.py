@@ -63,17 +63,26 @@ HP_CASES = [
     _c("hp_mdcn3d_c64_dg2_o64", M3, 1, 64, 64, (4, 5, 6), 3, dgroups=2, seed=142),
     _c("hp_dcn3d_c128_dg4_o64", D3, 1, 128, 64, (3, 6, 5), 3, dgroups=4, bias=False, seed=143),
     _c("hp_mdcn3d_c64_dg4_o32_big_offsets", M3, 2, 64, 32, (4, 4, 5), 3, dgroups=4, seed=144, offset_scale=3.0),
+    # group-padded layout (round 6, hp_host.hip group_padded): deformable groups of 24 / 48 / 80 / 40 / 12 channels run as groups
+    # of 32 / 64 / 128 / 64 / 16 with the padding channels zero; 2, 3 and 4 groups, 2-D and 3-D, with and without mask
+    _c("hp_mdcn2d_c96_dg4_o96_pad", M2, 2, 96, 96, (9, 10), 3, dgroups=4, seed=145),
+    _c("hp_dcn2d_c192_dg4_o64_pad", D2, 1, 192, 64, (8, 9), 3, dgroups=4, bias=False, seed=146),
+    _c("hp_mdcn2d_c160_dg2_o48_s2_pad", M2, 2, 160, 48, (12, 11), 3, stride=2, dgroups=2, seed=147),
+    _c("hp_mdcn2d_c72_dg3_o40_pad", M2, 2, 72, 40, (7, 9), 3, dgroups=3, seed=148),
+    _c("hp_mdcn3d_c48_dg2_o32_pad", M3, 1, 48, 32, (4, 5, 6), 3, dgroups=2, bias=False, seed=149),
+    _c("hp_dcn3d_c80_dg2_o64_dil2_pad", D3, 1, 80, 64, (4, 6, 5), 3, padding=2, dilation=2, dgroups=2, seed=150),
+    _c("hp_mdcn2d_c48_dg4_o64_big_offsets_pad", M2, 3, 48, 64, (8, 7), 3, dgroups=4, seed=151, offset_scale=4.0),
 ]
 
 CASE_BY_HP = {c["name"]: c for c in HP_CASES}
 
 # 16-bit shapes the native kernels reject in at least one direction (hp_supported): more than 256
-# input channels / a block's output range above 256 in the backward, three deformable groups of 16
-# channels (the pixel-stationary backward takes 1, 2 or 4 groups).  fp16 AND bf16 must still work (fp32 copies through the fp32 kernels, else the
+# input channels / a block's output range above 256 in the backward, deformable groups whose padded
+# form (group_padded, hp_host.hip) exceeds 256 channels.  fp16 AND bf16 must still work (fp32 copies through the fp32 kernels, else the
 # shape-generic kernels) -- ADVICE round 2: bf16 used to end in "unknown dtype 3".
 FALLBACK_CASES = [
     _c("fb_mdcn2d_c512_o64", M2, 1, 512, 64, (7, 6), 3, seed=131),
-    _c("fb_mdcn2d_c48_o64_dg3", M2, 2, 48, 64, (8, 7), 3, dgroups=3, seed=132),
+    _c("fb_mdcn2d_c320_o64_dg4", M2, 2, 320, 64, (8, 7), 3, dgroups=4, seed=132),   # groups of 80: padded to 128 = 512 channels
     _c("fb_dcn3d_c24_o8_g2", D3, 1, 24, 8, (4, 5, 4), 3, groups=2, bias=False, seed=133),
 ]
 
@@ -85,7 +94,10 @@ def _check(case, dtype, expect_hp=True, tol=None):
     torch.cuda.synchronize()
     # (with the older backward kernels forced -- tests/test_gpu_hp_forced.py -- deformable groups of 16 channels have no
     # native backward: only the pixel-stationary kernel takes them; the case still runs, on the fp32 kernels)
-    forced_old = os.environ.get("MDCONV_HP_BWD") in ("1", "2") and case["dgroups"] > 1 and (case["C"] // case["dgroups"]) % 32
+    cdg = case["C"] // case["dgroups"]
+    if case["name"].endswith("_pad"):   # the group size the kernels see
+        cdg = 1 << (cdg - 1).bit_length() if case["dgroups"] in (2, 4) else (cdg + 31) // 32 * 32
+    forced_old = os.environ.get("MDCONV_HP_BWD") in ("1", "2") and case["dgroups"] > 1 and cdg % 32
     if expect_hp and not forced_old:
         assert _capi.last_kernels() == "hp", (_capi.last_kernels(), paths)
     want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32)

@@ -9,7 +9,8 @@ extents (several 32-pixel tiles, ragged tile tails, batch tails), where the smal
           channels on 32-256 input channels, up to 256 output channels (run it with MDCONV_HP_BWD=4 so that small shapes take hp_bwd3 too).
 16-bit results are compared with the oracle whose `columns` / `grad_columns` are stored in the tensors' type, as the reference's are
 (oracle.backward(intermediates=...), mdeformable_conv.cu:396-397): the rounding the kernels share with the reference is not an error.
-usage: python tools/fuzz_more.py [--seconds 420] [--first 100] [--wide | --dg]      prints one line per failure and a summary."""
+  --pad:  16-bit shapes of the group-padded layout (deformable groups of 8 ... 120 channels run as groups of 16 ... 128)
+usage: python tools/fuzz_more.py [--seconds 420] [--first 100] [--wide | --dg | --pad]      prints one line per failure and a summary."""
 import os
 import random
 import sys
@@ -108,6 +109,18 @@ def case_hp_dg(seed):
               offset_scale=r.choice([0.5, 1.0, 3.0]))
 
 
+def case_hp_pad(seed):
+    """16-bit shapes of the group-padded layout: 2 / 3 / 4 deformable groups of 8 ... 120 channels that are not a size the kernels tile."""
+    r = random.Random(66000 + seed)
+    case = case_hp_dg(seed)
+    dg = r.choice([2, 2, 3, 4, 4])
+    cdg = r.choice([8, 12, 20, 24, 24, 40, 48, 48, 56, 72, 80, 96, 120])
+    while dg * (1 << (cdg - 1).bit_length() if dg != 3 else (cdg + 31) // 32 * 32) > 256:
+        cdg = r.choice([8, 12, 20, 24, 40, 48, 56])
+    case.update(name="padhp%d" % seed, C=dg * cdg, dgroups=dg)
+    return case
+
+
 GUARD = 1 << 16
 _guards = []
 
@@ -202,6 +215,8 @@ def main():
         first = int(a[a.index("--first") + 1])
     verbose = "--verbose" in a
     gen32, gen16 = (case_f32_wide, case_hp_wide) if "--wide" in a else ((case_f32, case_hp_dg) if "--dg" in a else (case_f32, case_hp))
+    if "--pad" in a:
+        gen16 = case_hp_pad
     t0 = time.time()
     n = [0, 0, 0]
     bad = 0
@@ -252,7 +267,9 @@ def main():
             print("run", dtype, case, flush=True)
         t = nan_margined(make_inputs(case, dtype=dtype, device="cuda"))
         out, grads, p = run_product(case, t, "auto")
-        paths[("16", ) + tuple(p)] = paths.get(("16", ) + tuple(p), 0) + 1
+        from modulated_deform_conv_amd import _capi
+        key16 = ("16", ) + tuple(p) + ("bwd:" + _capi.last_kernels(),)   # hp = native 16-bit backward, f32 = through fp32 copies
+        paths[key16] = paths.get(key16, 0) + 1
         want_out, want = run_oracle(case, {k: (None if v is None else v.float()) for k, v in t.items()}, torch.float32, intermediates=dtype)
         tol = 1e-2 if dtype == torch.float16 else 4e-2
 
