@@ -197,8 +197,8 @@ static void note_direct_fallback(const Geom &g, int dtype, bool backward, int pa
           "mdconv: %s of a %d-D shape with C_in=%d C_out=%d groups=%d deformable_groups=%d runs on the shape-generic "
           "kernels (the matrix-core kernels need %s); expect it to be ~10x slower. This note is printed once.\n",
           backward ? "backward" : "forward", g.nd, g.C, g.O, g.G, g.DG,
-          backward ? "C_in/deformable_groups a multiple of 8, at least 16, aligned with the conv groups"
-                   : "C_in/deformable_groups a multiple of 8, at least 16, aligned with the conv groups");
+          "with several deformable groups: one conv group and C_in/deformable_groups of at least 8, or with conv groups "
+          "C_in/deformable_groups a multiple of 8, at least 16, aligned with them");
 }
 
 static int require(const void *p, const char *name) {
@@ -419,6 +419,7 @@ size_t mdconv_workspace_bytes(const mdconv_desc *d, int backward) {
   Geom g;
   Modes md;
   if (fill_geom(d, &g) || call_modes(d, &md)) return 0;
+  g.in_cl = md.input_layout == MDCONV_LAYOUT_CHANNELS_LAST ? 1 : 0;   // (the plan of a channels-last call, where the caller says so)
   const bool half = d->dtype == MDCONV_F16 || d->dtype == MDCONV_BF16;
   const size_t direct = backward && half ? direct16_workspace_bytes(g) : 0;   // fp32 copies for the scatter kernels
   if (md.path == MDCONV_PATH_DIRECT) return direct;
@@ -446,6 +447,7 @@ int mdconv_input_layout_supported(const mdconv_desc *d, int layout, int backward
   if (fill_geom(d, &g) || call_modes(d, &md)) return 0;
   if (layout == MDCONV_LAYOUT_NCHW) return 1;
   if (layout != MDCONV_LAYOUT_CHANNELS_LAST) return 0;
+  g.in_cl = 1;   // the plan of a channels-last call (the group-padded layout needs the library's own input copy)
   return md.path != MDCONV_PATH_DIRECT && hp_supported(g, d->dtype, backward != 0) && g.C % 32 == 0;
 }
 

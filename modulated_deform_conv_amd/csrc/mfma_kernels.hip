@@ -4,6 +4,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <mutex>
@@ -917,8 +918,120 @@ int split_forward(const Geom &g, int dtype, const SplitFwdPlan &p, const Tensors
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// The same shapes as ONE padded problem (round 6): every deformable group widened to a size the kernels tile (forward: whole
+// 32-channel K stages; backward: 64 / 128 / n x 256 channels) with zero input planes and zero weight rows in between -- the
+// padding channels add nothing to any output, and their own gradient rows are never copied back.  One launch sequence over
+// C' = DG x padded-group channels instead of DG sequences over mostly-padding tiles plus their copies: faster on all 13 shapes
+// measured, 4x growth included (fp32, 4 groups: 64 -> 64 at 56 x 56, B = 16 1.44 -> 1.00 ms; 192 -> 192 at 20 x 20 0.70 -> 0.30;
+// 3-D 64 -> 64 2.41 -> 1.12; profiles/r06_experiments.md 18).  Taken when the padded problem is at most kPadMaxGrowth times
+// the caller's; one conv group only (conv groups keep the slices above).
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kPadMaxGrowth = 8;   // 16 -> 16 channels in 2 groups (8 -> 64, 8x): 0.39 ms on the shape-generic kernels, 0.25 padded
+struct PadPlan {
+  Geom gp;            // the padded problem: C = DG x cdp, C_dg = cdp
+  size_t off_x, off_w, off_gi, off_gw, off_sub, total;
+};
+// dst[r][0 .. dwidth) = src[r][0 .. width) followed by zeros (element = W)
+template <typename W>
+__global__ __launch_bounds__(256) void pad_rows_kernel(W *__restrict__ dst, int64_t dwidth, const W *__restrict__ src,
+                                                       int64_t width, int64_t rows) {
+  const int64_t n = dwidth * rows;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / dwidth, c = i - r * dwidth;
+    dst[i] = c < width ? src[r * width + c] : (W)0;
+  }
+}
+int pad_rows(void *dst, size_t dwidth, const void *src, size_t width, size_t rows, hipStream_t stream) {
+  const bool words = ((dwidth | width) & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 3) == 0;
+  const size_t es = words ? 4 : 2;
+  const int64_t n = (int64_t)(dwidth / es) * (int64_t)rows;
+  const int64_t blocks = (n + 255) / 256;
+  const dim3 grid((unsigned)(blocks > 16384 ? 16384 : (blocks < 1 ? 1 : blocks)));
+  if (words)
+    hipLaunchKernelGGL(pad_rows_kernel<unsigned>, grid, dim3(256), 0, stream, (unsigned *)dst, (int64_t)(dwidth / 4),
+                       (const unsigned *)src, (int64_t)(width / 4), (int64_t)rows);
+  else
+    hipLaunchKernelGGL(pad_rows_kernel<unsigned short>, grid, dim3(256), 0, stream, (unsigned short *)dst,
+                       (int64_t)(dwidth / 2), (const unsigned short *)src, (int64_t)(width / 2), (int64_t)rows);
+  return check_launch("pad_rows");
+}
+// MDCONV_DG_PLAN = pad | split forces one plan where both exist (developer A/B; default: by growth)
+int dg_plan_env() {
+  static const int v = [] {
+    const char *e = getenv("MDCONV_DG_PLAN");
+    return !e ? 0 : (!strcmp(e, "pad") ? 1 : (!strcmp(e, "split") ? 2 : 0));
+  }();
+  return v;
+}
+bool pad_plan(const Geom &g, int dtype, bool backward, PadPlan *p) {
+  if (g.G != 1 || g.DG <= 1 || dg_plan_env() == 2) return false;
+  int cdp;
+  if (backward) cdp = g.Cdg <= 64 ? 64 : (g.Cdg <= 128 ? 128 : (g.Cdg + 255) / 256 * 256);
+  else cdp = (g.Cdg + 2 * kBK - 1) / (2 * kBK) * (2 * kBK);
+  if (cdp == g.Cdg) return false;
+  if (dg_plan_env() != 1 && cdp > kPadMaxGrowth * g.Cdg) return false;
+  Geom gp = g;
+  gp.C = gp.Cg = g.DG * cdp;
+  gp.Cdg = cdp;
+  if (!native_supported(gp, dtype, backward)) return false;
+  p->gp = gp;
+  const size_t es = dtype == MDCONV_F32 ? 4 : 2;
+  size_t off = 0;
+  auto take = [&](size_t &slot, size_t elems) { slot = off; off += align_up(elems * es); };
+  take(p->off_x, (size_t)g.B * gp.C * g.S_i);
+  take(p->off_w, (size_t)g.O * gp.C * g.K);
+  take(p->off_gi, backward ? (size_t)g.B * gp.C * g.S_i : 0);
+  take(p->off_gw, backward ? (size_t)g.O * gp.C * g.K : 0);
+  p->off_sub = off;
+  p->total = off + native_workspace_bytes(gp, dtype, backward);
+  return true;
+}
+// input [B][DG][C_dg][S_i] -> [B][DG][cdp][S_i], weight [O][DG][C_dg][K] -> [O][DG][cdp][K]: rows of one (image | output
+// channel, group), contiguous on both sides
+int pad_inputs(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, char *base, hipStream_t stream) {
+  const size_t es = dtype == MDCONV_F32 ? 4 : 2;
+  int rc;
+  if ((rc = pad_rows(base + p.off_x, (size_t)p.gp.Cdg * g.S_i * es, t.input, (size_t)g.Cdg * g.S_i * es, (size_t)g.B * g.DG, stream)))
+    return rc;
+  return pad_rows(base + p.off_w, (size_t)p.gp.Cdg * g.K * es, t.weight, (size_t)g.Cdg * g.K * es, (size_t)g.O * g.DG, stream);
+}
+int pad_forward(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, void *ws, hipStream_t stream) {
+  char *base = (char *)ws;
+  int rc;
+  if ((rc = pad_inputs(g, dtype, p, t, base, stream))) return rc;
+  Tensors tp = t;
+  tp.input = base + p.off_x;
+  tp.weight = base + p.off_w;
+  return native_forward(p.gp, dtype, tp, base + p.off_sub, stream);
+}
+int pad_backward(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, void *ws, hipStream_t stream) {
+  char *base = (char *)ws;
+  const size_t es = dtype == MDCONV_F32 ? 4 : 2;
+  const size_t w_x = (size_t)g.Cdg * g.S_i * es, p_x = (size_t)p.gp.Cdg * g.S_i * es;
+  const size_t w_w = (size_t)g.Cdg * g.K * es, p_w = (size_t)p.gp.Cdg * g.K * es;
+  int rc;
+  if ((rc = pad_inputs(g, dtype, p, t, base, stream))) return rc;
+  // accumulate modes: the padded gradient buffers start from the caller's values (like the slices above)
+  if (g.acc_data && (rc = pad_rows(base + p.off_gi, p_x, t.grad_input, w_x, (size_t)g.B * g.DG, stream))) return rc;
+  if (g.acc_w && (rc = pad_rows(base + p.off_gw, p_w, t.grad_weight, w_w, (size_t)g.O * g.DG, stream))) return rc;
+  Tensors tp = t;   // grad_offset / grad_mask / grad_bias have no channel axis: written in place, in the caller's mode
+  tp.input = base + p.off_x;
+  tp.weight = base + p.off_w;
+  tp.grad_input = base + p.off_gi;
+  tp.grad_weight = base + p.off_gw;
+  if ((rc = native_backward(p.gp, dtype, tp, base + p.off_sub, stream))) return rc;
+  if ((rc = copy_rows(t.grad_input, w_x, base + p.off_gi, p_x, w_x, (size_t)g.B * g.DG, stream))) return rc;
+  if ((rc = copy_rows(t.grad_weight, w_w, base + p.off_gw, p_w, w_w, (size_t)g.O * g.DG, stream))) return rc;
+  return record_weight_ready(stream);   // after the copy back
+}
+}  // namespace
+
 bool mfma_supported(const Geom &g, int dtype, bool backward) {
   if (native_supported(g, dtype, backward)) return true;
+  PadPlan pp;
+  if (pad_plan(g, dtype, backward, &pp)) return true;
   SplitPlan p;
   SplitFwdPlan pf;
   return backward ? split_plan(g, dtype, &p) : split_fwd_plan(g, dtype, &pf);
@@ -926,6 +1039,8 @@ bool mfma_supported(const Geom &g, int dtype, bool backward) {
 
 size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
   if (native_supported(g, dtype, backward)) return native_workspace_bytes(g, dtype, backward);
+  PadPlan pp;
+  if (pad_plan(g, dtype, backward, &pp)) return pp.total;
   SplitPlan p;
   SplitFwdPlan pf;
   if (backward) return split_plan(g, dtype, &p) ? p.total : 0;
@@ -934,6 +1049,8 @@ size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
 
 int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
   if (native_supported(g, dtype, false)) return native_forward(g, dtype, t, ws, stream);
+  PadPlan pp;
+  if (pad_plan(g, dtype, false, &pp)) return pad_forward(g, dtype, pp, t, ws, stream);
   SplitFwdPlan p;
   if (!split_fwd_plan(g, dtype, &p)) { set_error("mfma_forward: no plan"); return MDCONV_EUNSUPPORTED; }
   return split_forward(g, dtype, p, t, ws, stream);
@@ -941,6 +1058,8 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
 
 int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
   if (native_supported(g, dtype, true)) return native_backward(g, dtype, t, ws, stream);
+  PadPlan pp;
+  if (pad_plan(g, dtype, true, &pp)) return pad_backward(g, dtype, pp, t, ws, stream);
   SplitPlan p;
   if (!split_plan(g, dtype, &p)) { set_error("mfma_backward: no plan"); return MDCONV_EUNSUPPORTED; }
   return split_backward(g, dtype, p, t, ws, stream);

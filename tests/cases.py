@@ -60,6 +60,14 @@ CASES = [
     _c("mfma_split_dcn3d_s2_dg2_c48_o24", D3, 1, 48, 24, (7, 6, 7), 3, stride=2, dgroups=2, tier="medium", seed=75),
     _c("mfma_split_mdcn2d_dg8_c128_o32", M2, 2, 128, 32, (9, 10), 3, dgroups=8, tier="medium", seed=76),
     _c("mfma_split_dcn3d_g2_dg8_c128_o32", D3, 1, 128, 32, (5, 5, 6), 3, groups=2, dgroups=8, in_step=1, tier="medium", seed=77),
+    # ... and as ONE padded problem (round 6, pad_plan: every group widened to 32-channel stages forward, 64 / 128 / n x 256
+    # channels backward; the default with one conv group): groups of 8 / 24 / 40 / 80 / 136 channels, 2-D / 3-D, 2 - 5 groups
+    _c("mfma_pad_mdcn2d_dg4_c96_o64", M2, 2, 96, 64, (11, 10), 3, dgroups=4, tier="medium", seed=78),
+    _c("mfma_pad_dcn2d_dg2_c16_o16", D2, 3, 16, 16, (12, 13), 3, dgroups=2, in_step=1, bias=False, tier="medium", seed=79),
+    _c("mfma_pad_mdcn2d_dg5_c200_o48_s2", M2, 2, 200, 48, (13, 12), 3, stride=2, dgroups=5, tier="medium", seed=80),
+    _c("mfma_pad_dcn3d_dg2_c160_o32", D3, 1, 160, 32, (4, 5, 6), 3, dgroups=2, tier="medium", seed=81),
+    _c("mfma_pad_mdcn3d_dg3_c72_o40_dil2", M3, 2, 72, 40, (5, 6, 5), 3, padding=2, dilation=2, dgroups=3, in_step=1, tier="medium", seed=82),
+    _c("mfma_pad_mdcn2d_dg2_c272_o32", M2, 1, 272, 32, (7, 8), 3, dgroups=2, bias=False, tier="medium", seed=83),
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),
