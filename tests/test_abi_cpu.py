@@ -219,6 +219,15 @@ def test_workspace_plan_and_layout_query_without_gpu(capi):
     assert cl(dg16, 0) == 1 and cl(dg16, 1) == 1                              # round 6: the pixel-stationary backward takes them
     dg6 = _plan_desc(capi, 2, capi.F16, 2, 96, 64, (8, 8), DG=6)              # 6 groups of 16 channels: forward only
     assert cl(dg6, 0) == 1 and cl(dg6, 1) == 0 and ws(dg6, 1) > 0             # backward: fp32 kernels / shape-generic kernels on fp32 copies
+    # groups of 24 channels (round 6): group-padded on the native kernels, which need the library's own (128-wide) input copy
+    pad24 = _plan_desc(capi, 2, capi.F16, 2, 96, 64, (8, 8), DG=4)
+    assert cl(pad24, 0) == 0 and cl(pad24, 1) == 0
+    assert ws(pad24, 0) >= 2 * 64 * 128 * 2 and ws(pad24, 1) >= 2 * 64 * 128 * 2 + 2 * 9 * 64 * 128 * 2   # xt; xt + grad_col rows
+    pad24.input_layout = capi.LAYOUT_CHANNELS_LAST if hasattr(capi, "LAYOUT_CHANNELS_LAST") else 1
+    assert ws(pad24, 1) >= 0                                                  # (a refused call: any answer, no crash)
+    # the same in fp32: ONE padded problem (groups of 64 in the backward = 256 channels): copies of input / weight + their gradients
+    f32pad = _plan_desc(capi, 2, capi.F32, 2, 96, 64, (8, 8), DG=4)
+    assert ws(f32pad, 1) >= (2 * 2 * 256 * 64 + 2 * 64 * 256 * 9) * 4
     assert L.mdconv_input_layout_supported(ctypes.byref(cfg5), 0, 1) == 1    # NCHW always
     assert L.mdconv_input_layout_supported(ctypes.byref(cfg5), 7, 1) == 0
     assert capi.lib().mdconv_profile_name(9) == b""
