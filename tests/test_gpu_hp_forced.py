@@ -46,7 +46,9 @@ from tests.util import assert_close, run_oracle, run_product
 from modulated_deform_conv_amd import _capi
 cases = {"2d_fp16": (_c("chunk_mdcn2d_c64_o64", M2, 20, 64, 64, (24, 20), 3, seed=141), torch.float16, False),
          "2d_bf16_cl": (_c("chunk_mdcn2d_c64_o64_cl", M2, 20, 64, 64, (24, 20), 3, seed=141), torch.bfloat16, True),
-         "3d_fp16": (_c("chunk_mdcn3d_c32_o32", M3, 30, 32, 32, (4, 8, 8), 3, seed=142), torch.float16, False)}
+         "3d_fp16": (_c("chunk_mdcn3d_c32_o32", M3, 30, 32, 32, (4, 8, 8), 3, seed=142), torch.float16, False),
+         # group-padded layout (2 groups of 24 channels run as 2 x 32): chunk pointers step by the CALLER's 48 channels
+         "2d_fp16_pad": (_c("chunk_mdcn2d_c48_dg2_o64", M2, 20, 48, 64, (24, 20), 3, dgroups=2, seed=143), torch.float16, False)}
 case, dtype, cl = cases[sys.argv[1]]
 t = make_inputs(case, dtype=dtype, device="cuda")
 if cl:
@@ -68,7 +70,7 @@ print("HP_CHUNK_OK")
 # go below the latter: 2-D 9 * 480 * 64 * 2 = 552 960 B (input copy 61 440 B per image -> 9 images
 # per chunk, B = 20 -> chunks of 9, 9, 2); 3-D 27 * 256 * 32 * 2 = 442 368 B (16 384 B per image ->
 # 27 per chunk, B = 30 -> 27 + 3).  The last chunk is shorter in every case.
-@pytest.mark.parametrize("which, limit", [("2d_fp16", 600_000), ("2d_bf16_cl", 600_000), ("3d_fp16", 450_000)])
+@pytest.mark.parametrize("which, limit", [("2d_fp16", 600_000), ("2d_bf16_cl", 600_000), ("3d_fp16", 450_000), ("2d_fp16_pad", 600_000)])
 def test_16bit_batch_chunk_loop_with_uneven_chunks(which, limit):
     env = dict(os.environ, MDCONV_CHUNK_LIMIT_BYTES=str(limit))
     r = subprocess.run([sys.executable, "-c", CHUNK_CODE % ROOT, which], env=env, capture_output=True,

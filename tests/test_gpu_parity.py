@@ -168,6 +168,10 @@ print("CHUNK_OK")
     ("mfma_split_dcn2d_g2_dg4_c128_o64", torch.float32, "auto"),
     ("mfma_split_mdcn3d_dg2_c32_o32", torch.float32, "auto"),
     ("mfma_split_mdcn3d_dg2_c32_o32", torch.bfloat16, "auto"),
+    ("mfma_pad_dcn3d_dg2_c160_o32", torch.float32, "auto"),     # one padded problem: gradients copied back from padded buffers
+    ("mfma_pad_dcn2d_dg2_c16_o16", torch.float32, "auto"),
+    ("mfma_pad_dcn3d_dg2_c160_o32", torch.float16, "auto"),     # group-padded layout on the native 16-bit kernels (80 -> 128)
+    ("mfma_pad_mdcn3d_dg3_c72_o40_dil2", torch.float16, "auto"),
 ])
 def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
     """mdconv_set_accumulate(0): the caller-allocated backward entry points must WRITE every element
