@@ -232,6 +232,7 @@ static bool group_padded(const Geom &g, Geom *gv) {
   int cdp = (g.DG == 2 || g.DG == 4) ? pow2_ceil(g.Cdg) : (g.Cdg + 31) / 32 * 32;
   if (cdp < 16) cdp = 16;
   if (cdp == g.Cdg) return false;
+  if (cdp > 8 * g.Cdg) return false;   // single-channel groups: 16x the gather work loses to the shape-generic kernels (0.74 vs 0.56 ms)
   *gv = g;
   gv->C = gv->Cg = g.DG * cdp;
   gv->Cdg = cdp;

@@ -924,11 +924,13 @@ int split_forward(const Geom &g, int dtype, const SplitFwdPlan &p, const Tensors
 // padding channels add nothing to any output, and their own gradient rows are never copied back.  One launch sequence over
 // C' = DG x padded-group channels instead of DG sequences over mostly-padding tiles plus their copies: faster on all 13 shapes
 // measured, 4x growth included (fp32, 4 groups: 64 -> 64 at 56 x 56, B = 16 1.44 -> 1.00 ms; 192 -> 192 at 20 x 20 0.70 -> 0.30;
-// 3-D 64 -> 64 2.41 -> 1.12; profiles/r06_experiments.md 18).  Taken when the padded problem is at most kPadMaxGrowth times
-// the caller's; one conv group only (conv groups keep the slices above).
+// 3-D 64 -> 64 2.41 -> 1.12; profiles/r06_experiments.md 18).  Taken when the padded problem is at most a few times
+// the caller's (kPadMaxGrowthFwd / Bwd); one conv group only (conv groups keep the slices above).
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int kPadMaxGrowth = 8;   // 16 -> 16 channels in 2 groups (8 -> 64, 8x): 0.39 ms on the shape-generic kernels, 0.25 padded
+// 16 -> 16 channels in 2 groups (8 -> 32 forward, 8 -> 64 backward): 0.39 ms on the shape-generic kernels, 0.25 padded; groups of 4
+// (8x forward, 16x backward) are faster left alone (16 -> 16 in 4 groups: 0.57 ms generic, 0.60 with a padded forward)
+constexpr int kPadMaxGrowthFwd = 4, kPadMaxGrowthBwd = 8;
 struct PadPlan {
   Geom gp;            // the padded problem: C = DG x cdp, C_dg = cdp
   size_t off_x, off_w, off_gi, off_gw, off_sub, total;
@@ -971,7 +973,7 @@ bool pad_plan(const Geom &g, int dtype, bool backward, PadPlan *p) {
   if (backward) cdp = g.Cdg <= 64 ? 64 : (g.Cdg <= 128 ? 128 : (g.Cdg + 255) / 256 * 256);
   else cdp = (g.Cdg + 2 * kBK - 1) / (2 * kBK) * (2 * kBK);
   if (cdp == g.Cdg) return false;
-  if (dg_plan_env() != 1 && cdp > kPadMaxGrowth * g.Cdg) return false;
+  if (dg_plan_env() != 1 && cdp > (backward ? kPadMaxGrowthBwd : kPadMaxGrowthFwd) * g.Cdg) return false;
   Geom gp = g;
   gp.C = gp.Cg = g.DG * cdp;
   gp.Cdg = cdp;
