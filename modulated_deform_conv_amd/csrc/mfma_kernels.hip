@@ -967,13 +967,33 @@ int dg_plan_env() {
   }();
   return v;
 }
+// ONE deformable group, one conv group, and a channel count that is not a multiple of the 64-channel slab of the channels-last
+// kernels: such shapes are tiled natively, but by the NCHW kernels, whose 2^nd corner loads go to one channel PLANE each.  Padded
+// to the next multiple of 64 (zero planes / zero weight rows, the same plan as for deformable groups) they run on the
+// channels-last kernels instead.  3-D from 16 channels and 2048 output pixels (11 shapes, profiles/r06_experiments.md 22:
+// 32 -> 64 at 16 x 56 x 56, B = 2: 3.33 -> 1.80 ms; 16 -> 16 at 16 x 32 x 32: 0.98 -> 0.72; 48 -> 48 at 8 x 28 x 28: 0.63 -> 0.45;
+// 160 channels at 1568 pixels: +7 %, hence the pixel floor); 2-D only below 64 channels where the backward would take the
+// channels-last kernels anyway (48 -> 48 at 56 x 56, B = 16: 0.41 -> 0.34 ms; 96 / 160 channels lose 10-15 %).
+// MDCONV_PAD_CHANNELS = 0 | 1: never / wherever eligible (the test suite's way to reach the plan with small shapes).
+bool pad_channels_preferred(const Geom &g) {
+  static const int env = getenv("MDCONV_PAD_CHANNELS") ? atoi(getenv("MDCONV_PAD_CHANNELS")) : -1;
+  if (env == 0 || g.G != 1 || g.DG != 1 || g.C % 64 == 0 || g.C < 16) return false;
+  if (env > 0) return true;
+  if (g.nd == 3) return g.N >= 2048;
+  return g.C >= 32 && g.C < 64 && g.N >= 8192;
+}
 bool pad_plan(const Geom &g, int dtype, bool backward, PadPlan *p) {
-  if (g.G != 1 || g.DG <= 1 || dg_plan_env() == 2) return false;
+  if (g.G != 1 || dg_plan_env() == 2) return false;
   int cdp;
-  if (backward) cdp = g.Cdg <= 64 ? 64 : (g.Cdg <= 128 ? 128 : (g.Cdg + 255) / 256 * 256);
-  else cdp = (g.Cdg + 2 * kBK - 1) / (2 * kBK) * (2 * kBK);
-  if (cdp == g.Cdg) return false;
-  if (dg_plan_env() != 1 && cdp > (backward ? kPadMaxGrowthBwd : kPadMaxGrowthFwd) * g.Cdg) return false;
+  if (g.DG == 1) {
+    if (!pad_channels_preferred(g)) return false;
+    cdp = (g.C + 63) / 64 * 64;
+  } else {
+    if (backward) cdp = g.Cdg <= 64 ? 64 : (g.Cdg <= 128 ? 128 : (g.Cdg + 255) / 256 * 256);
+    else cdp = (g.Cdg + 2 * kBK - 1) / (2 * kBK) * (2 * kBK);
+    if (cdp == g.Cdg) return false;
+    if (dg_plan_env() != 1 && cdp > (backward ? kPadMaxGrowthBwd : kPadMaxGrowthFwd) * g.Cdg) return false;
+  }
   Geom gp = g;
   gp.C = gp.Cg = g.DG * cdp;
   gp.Cdg = cdp;
@@ -1030,6 +1050,13 @@ int pad_backward(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, v
 }
 }  // namespace
 
+// native tiling unless the padded problem is the faster one (pad_channels_preferred)
+static bool run_native(const Geom &g, int dtype, bool backward) {
+  PadPlan pp;
+  if (pad_channels_preferred(g) && pad_plan(g, dtype, backward, &pp)) return false;
+  return native_supported(g, dtype, backward);
+}
+
 bool mfma_supported(const Geom &g, int dtype, bool backward) {
   if (native_supported(g, dtype, backward)) return true;
   PadPlan pp;
@@ -1040,7 +1067,7 @@ bool mfma_supported(const Geom &g, int dtype, bool backward) {
 }
 
 size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
-  if (native_supported(g, dtype, backward)) return native_workspace_bytes(g, dtype, backward);
+  if (run_native(g, dtype, backward)) return native_workspace_bytes(g, dtype, backward);
   PadPlan pp;
   if (pad_plan(g, dtype, backward, &pp)) return pp.total;
   SplitPlan p;
@@ -1050,7 +1077,7 @@ size_t mfma_workspace_bytes(const Geom &g, int dtype, bool backward) {
 }
 
 int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
-  if (native_supported(g, dtype, false)) return native_forward(g, dtype, t, ws, stream);
+  if (run_native(g, dtype, false)) return native_forward(g, dtype, t, ws, stream);
   PadPlan pp;
   if (pad_plan(g, dtype, false, &pp)) return pad_forward(g, dtype, pp, t, ws, stream);
   SplitFwdPlan p;
@@ -1059,7 +1086,7 @@ int mfma_forward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream
 }
 
 int mfma_backward(const Geom &g, int dtype, const Tensors &t, void *ws, hipStream_t stream) {
-  if (native_supported(g, dtype, true)) return native_backward(g, dtype, t, ws, stream);
+  if (run_native(g, dtype, true)) return native_backward(g, dtype, t, ws, stream);
   PadPlan pp;
   if (pad_plan(g, dtype, true, &pp)) return pad_backward(g, dtype, pp, t, ws, stream);
   SplitPlan p;

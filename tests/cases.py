@@ -68,6 +68,13 @@ CASES = [
     _c("mfma_pad_dcn3d_dg2_c160_o32", D3, 1, 160, 32, (4, 5, 6), 3, dgroups=2, tier="medium", seed=81),
     _c("mfma_pad_mdcn3d_dg3_c72_o40_dil2", M3, 2, 72, 40, (5, 6, 5), 3, padding=2, dilation=2, dgroups=3, in_step=1, tier="medium", seed=82),
     _c("mfma_pad_mdcn2d_dg2_c272_o32", M2, 1, 272, 32, (7, 8), 3, dgroups=2, bias=False, tier="medium", seed=83),
+    # one deformable group, C_in not a multiple of 64, enough pixels (3-D: 2048, 2-D below 64 channels: 8192): the padded plan
+    # again, so that the channels-last kernels take the shape (round 6, pad_channels_preferred)
+    _c("mfma_padc_mdcn3d_c32_o32_2304px", M3, 2, 32, 32, (8, 12, 12), 3, tier="medium", seed=84),
+    _c("mfma_padc_dcn3d_c48_o24_s2", D3, 1, 48, 24, (14, 24, 25), 3, stride=2, in_step=1, bias=False, tier="medium", seed=85),
+    _c("mfma_padc_mdcn3d_c16_o16_dil2", M3, 1, 16, 16, (10, 15, 16), 3, padding=2, dilation=2, tier="medium", seed=86),
+    _c("mfma_padc_mdcn3d_c96_o40", M3, 1, 96, 40, (6, 18, 20), 3, tier="medium", seed=87),
+    _c("mfma_padc_mdcn2d_c48_o32_9408px", M2, 3, 48, 32, (56, 56), 3, tier="medium", seed=88),
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),

@@ -21,3 +21,17 @@ def test_parity_with_the_deformable_group_plan_forced(plan):
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("on", ["1", "0"])
+def test_parity_with_channel_padding_forced(on):
+    """One deformable group and C_in not a multiple of 64: padded to 64 channels the shape runs on the channels-last fp32 kernels
+    (mfma_kernels.hip, pad_channels_preferred: 3-D from 2048 pixels, narrow 2-D from 8192).  MDCONV_PAD_CHANNELS = 1 takes the
+    plan for every eligible shape, 0 for none: the matrix-path parity cases and the fp32 random shapes run under both."""
+    env = dict(os.environ, MDCONV_PAD_CHANNELS=on)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_fuzz.py", "-m", "gpu", "-q", "-x",
+                        "-k", "mfma_path or auto_path or overwrite or non_finite or mfma_equals_direct or wide_geometry_fp32"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
