@@ -932,8 +932,9 @@ namespace {
 // (8x forward, 16x backward) are faster left alone (16 -> 16 in 4 groups: 0.57 ms generic, 0.60 with a padded forward)
 constexpr int kPadMaxGrowthFwd = 4, kPadMaxGrowthBwd = 8;
 struct PadPlan {
-  Geom gp;            // the padded problem: C = DG x cdp, C_dg = cdp
-  size_t off_x, off_w, off_gi, off_gw, off_sub, total;
+  Geom gp;            // the padded problem: C = DG x cdp, C_dg = cdp, O = Op
+  bool pad_c, pad_o;  // input channels / output channels padded
+  size_t off_x, off_w, off_gi, off_gw, off_o, off_b, off_gb, off_sub, total;   // off_o: output (forward) / grad_output (backward)
 };
 // dst[r][0 .. dwidth) = src[r][0 .. width) followed by zeros (element = W)
 template <typename W>
@@ -967,85 +968,141 @@ int dg_plan_env() {
   }();
   return v;
 }
-// ONE deformable group, one conv group, and a channel count that is not a multiple of the 64-channel slab of the channels-last
-// kernels: such shapes are tiled natively, but by the NCHW kernels, whose 2^nd corner loads go to one channel PLANE each.  Padded
-// to the next multiple of 64 (zero planes / zero weight rows, the same plan as for deformable groups) they run on the
-// channels-last kernels instead.  3-D from 16 channels and 2048 output pixels (11 shapes, profiles/r06_experiments.md 22:
-// 32 -> 64 at 16 x 56 x 56, B = 2: 3.33 -> 1.80 ms; 16 -> 16 at 16 x 32 x 32: 0.98 -> 0.72; 48 -> 48 at 8 x 28 x 28: 0.63 -> 0.45;
-// 160 channels at 1568 pixels: +7 %, hence the pixel floor); 2-D only below 64 channels where the backward would take the
-// channels-last kernels anyway (48 -> 48 at 56 x 56, B = 16: 0.41 -> 0.34 ms; 96 / 160 channels lose 10-15 %).
+// ONE deformable group and one conv group: two kinds of shapes run as a padded problem although nothing about their groups
+// needs it (profiles/r06_experiments.md 22, 23).
+//  * C_in not a multiple of the 64-channel slab of the channels-last kernels.  Such shapes are tiled natively, but by the NCHW
+//    kernels, whose 2^nd corner loads go to one channel PLANE each; padded to the next multiple of 64 they take the channels-last
+//    kernels.  3-D from 2048 output pixels (32 -> 64 at 16 x 56 x 56, B = 2: 3.33 -> 1.80 ms; 16 -> 16 at 16 x 32 x 32: 0.98 -> 0.72;
+//    160 channels at 1568 pixels: +7 %, hence the floor); 2-D only for 32 <= C_in < 64 from 8192 pixels, where the backward is
+//    channels-last anyway (48 -> 48 at 56 x 56, B = 16: 0.41 -> 0.34 ms; 96 / 160 channels lose 10-15 %).
+//  * Fewer than 16 input or output channels: below the matrix kernels' floor, i.e. the shape-generic kernels -- whose cost grows
+//    with C_in x C_out x taps per thread.  Output channels are padded to 16 (zero weight rows, zero grad_output planes, a
+//    workspace tile for the output), input channels to 64: 3-D 64 -> 8 at 8 x 28 x 28: 6.92 -> 0.45 ms, 2-D 64 -> 8 at 56 x 56,
+//    B = 16: 3.08 -> 0.32 ms, 3-D 8 -> 8 at 16 x 32 x 32: 1.81 -> 0.73 ms, 2-D 8 -> 8 at 112 x 112, B = 8: 0.81 -> 0.57 ms.  Not for
+//    grids of a few hundred pixels (4 -> 4 at 8 x 8, BASELINE configs[0]: 0.13 ms generic, 0.21 padded), nor in 2-D below 8 input
+//    channels (3 -> 16 at 112 x 112: 0.38 -> 0.55 ms) or 8192 pixels (ties).
 // MDCONV_PAD_CHANNELS = 0 | 1: never / wherever eligible (the test suite's way to reach the plan with small shapes).
 bool pad_channels_preferred(const Geom &g) {
   static const int env = getenv("MDCONV_PAD_CHANNELS") ? atoi(getenv("MDCONV_PAD_CHANNELS")) : -1;
-  if (env == 0 || g.G != 1 || g.DG != 1 || g.C % 64 == 0 || g.C < 16) return false;
+  if (env == 0 || g.G != 1 || g.DG != 1) return false;
+  const bool tiny_c = g.C < 16, tiny_o = g.O < 16;
+  if (!tiny_c && !tiny_o && g.C % 64 == 0) return false;
   if (env > 0) return true;
+  if (tiny_c) return g.nd == 3 ? g.N >= 512 : (g.C >= 8 && g.N >= 8192);
+  if (tiny_o) return g.N >= 512;
   if (g.nd == 3) return g.N >= 2048;
   return g.C >= 32 && g.C < 64 && g.N >= 8192;
 }
+// padded channels of one deformable group for the plan of `g` (0 = no plan)
+static int pad_group_channels(const Geom &g, bool backward) {
+  if (g.DG == 1) {
+    if (!pad_channels_preferred(g)) return 0;
+    if (g.C % 64 == 0) return g.C;
+    const bool to_slab = g.nd == 3 || g.C < 16 || (g.C >= 32 && g.C < 64 && g.N >= 8192);
+    return to_slab ? (g.C + 63) / 64 * 64 : (g.C + 7) / 8 * 8;   // (else only C_out is padded: the NCHW kernels need 8 | C_in)
+  }
+  int cdp;
+  if (backward) cdp = g.Cdg <= 64 ? 64 : (g.Cdg <= 128 ? 128 : (g.Cdg + 255) / 256 * 256);
+  else cdp = (g.Cdg + 2 * kBK - 1) / (2 * kBK) * (2 * kBK);
+  if (cdp == g.Cdg) return 0;
+  if (dg_plan_env() != 1 && cdp > (backward ? kPadMaxGrowthBwd : kPadMaxGrowthFwd) * g.Cdg) return 0;
+  return cdp;
+}
 bool pad_plan(const Geom &g, int dtype, bool backward, PadPlan *p) {
   if (g.G != 1 || dg_plan_env() == 2) return false;
-  int cdp;
-  if (g.DG == 1) {
-    if (!pad_channels_preferred(g)) return false;
-    cdp = (g.C + 63) / 64 * 64;
-  } else {
-    if (backward) cdp = g.Cdg <= 64 ? 64 : (g.Cdg <= 128 ? 128 : (g.Cdg + 255) / 256 * 256);
-    else cdp = (g.Cdg + 2 * kBK - 1) / (2 * kBK) * (2 * kBK);
-    if (cdp == g.Cdg) return false;
-    if (dg_plan_env() != 1 && cdp > (backward ? kPadMaxGrowthBwd : kPadMaxGrowthFwd) * g.Cdg) return false;
-  }
+  const int cdp = pad_group_channels(g, backward);
+  if (cdp == 0) return false;
+  const int Op = g.DG == 1 && g.O < 16 ? 16 : g.O;   // (only the one-group plan pads the output channels)
+  p->pad_c = cdp != g.Cdg;
+  p->pad_o = Op != g.O;
+  if (!p->pad_c && !p->pad_o) return false;
   Geom gp = g;
   gp.C = gp.Cg = g.DG * cdp;
   gp.Cdg = cdp;
+  gp.O = gp.Og = Op;
   if (!native_supported(gp, dtype, backward)) return false;
   p->gp = gp;
   const size_t es = dtype == MDCONV_F32 ? 4 : 2;
   size_t off = 0;
   auto take = [&](size_t &slot, size_t elems) { slot = off; off += align_up(elems * es); };
-  take(p->off_x, (size_t)g.B * gp.C * g.S_i);
-  take(p->off_w, (size_t)g.O * gp.C * g.K);
-  take(p->off_gi, backward ? (size_t)g.B * gp.C * g.S_i : 0);
-  take(p->off_gw, backward ? (size_t)g.O * gp.C * g.K : 0);
+  take(p->off_x, p->pad_c ? (size_t)g.B * gp.C * g.S_i : 0);
+  take(p->off_w, (size_t)Op * gp.C * g.K);
+  take(p->off_gi, backward && p->pad_c ? (size_t)g.B * gp.C * g.S_i : 0);
+  take(p->off_gw, backward ? (size_t)Op * gp.C * g.K : 0);
+  take(p->off_o, p->pad_o ? (size_t)g.B * Op * g.S_o : 0);
+  take(p->off_b, p->pad_o && g.with_bias && !backward ? (size_t)Op : 0);
+  take(p->off_gb, p->pad_o && g.with_bias && backward ? (size_t)Op : 0);
   p->off_sub = off;
   p->total = off + native_workspace_bytes(gp, dtype, backward);
   return true;
 }
-// input [B][DG][C_dg][S_i] -> [B][DG][cdp][S_i], weight [O][DG][C_dg][K] -> [O][DG][cdp][K]: rows of one (image | output
-// channel, group), contiguous on both sides
-int pad_inputs(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, char *base, hipStream_t stream) {
+// input [B][DG][C_dg][S_i] -> [B][DG][cdp][S_i], weight [O][DG][C_dg][K] -> [Op][DG][cdp][K] (rows O .. Op - 1 zero): rows of one
+// (image | output channel, group), contiguous on both sides
+int pad_inputs(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, char *base, Tensors *tp, hipStream_t stream) {
   const size_t es = dtype == MDCONV_F32 ? 4 : 2;
   int rc;
-  if ((rc = pad_rows(base + p.off_x, (size_t)p.gp.Cdg * g.S_i * es, t.input, (size_t)g.Cdg * g.S_i * es, (size_t)g.B * g.DG, stream)))
+  if (p.pad_c) {
+    if ((rc = pad_rows(base + p.off_x, (size_t)p.gp.Cdg * g.S_i * es, t.input, (size_t)g.Cdg * g.S_i * es, (size_t)g.B * g.DG, stream)))
+      return rc;
+    tp->input = base + p.off_x;
+  }
+  if ((rc = pad_rows(base + p.off_w, (size_t)p.gp.Cdg * g.K * es, t.weight, (size_t)g.Cdg * g.K * es, (size_t)g.O * g.DG, stream)))
     return rc;
-  return pad_rows(base + p.off_w, (size_t)p.gp.Cdg * g.K * es, t.weight, (size_t)g.Cdg * g.K * es, (size_t)g.O * g.DG, stream);
+  if (p.pad_o) {
+    const size_t row = (size_t)p.gp.C * g.K * es;
+    if ((rc = pad_rows(base + p.off_w + (size_t)g.O * row, (size_t)(p.gp.O - g.O) * row, t.weight, 0, 1, stream))) return rc;
+  }
+  tp->weight = base + p.off_w;
+  return MDCONV_OK;
 }
 int pad_forward(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, void *ws, hipStream_t stream) {
   char *base = (char *)ws;
+  const size_t es = dtype == MDCONV_F32 ? 4 : 2;
   int rc;
-  if ((rc = pad_inputs(g, dtype, p, t, base, stream))) return rc;
   Tensors tp = t;
-  tp.input = base + p.off_x;
-  tp.weight = base + p.off_w;
-  return native_forward(p.gp, dtype, tp, base + p.off_sub, stream);
+  if ((rc = pad_inputs(g, dtype, p, t, base, &tp, stream))) return rc;
+  if (p.pad_o) {   // the kernels write Op output channels (and read Op bias values): a workspace tile, the real rows copied out
+    if (g.with_bias) {
+      if ((rc = pad_rows(base + p.off_b, (size_t)p.gp.O * es, t.bias, (size_t)g.O * es, 1, stream))) return rc;
+      tp.bias = base + p.off_b;
+    }
+    tp.output = base + p.off_o;
+  }
+  if ((rc = native_forward(p.gp, dtype, tp, base + p.off_sub, stream))) return rc;
+  if (!p.pad_o) return MDCONV_OK;
+  const size_t w_o = (size_t)g.O * g.S_o * es;
+  return copy_rows(t.output, w_o, base + p.off_o, (size_t)p.gp.O * g.S_o * es, w_o, g.B, stream);
 }
 int pad_backward(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, void *ws, hipStream_t stream) {
   char *base = (char *)ws;
   const size_t es = dtype == MDCONV_F32 ? 4 : 2;
   const size_t w_x = (size_t)g.Cdg * g.S_i * es, p_x = (size_t)p.gp.Cdg * g.S_i * es;
   const size_t w_w = (size_t)g.Cdg * g.K * es, p_w = (size_t)p.gp.Cdg * g.K * es;
+  const size_t w_o = (size_t)g.O * g.S_o * es, p_o = (size_t)p.gp.O * g.S_o * es;
   int rc;
-  if ((rc = pad_inputs(g, dtype, p, t, base, stream))) return rc;
+  Tensors tp = t;   // grad_offset / grad_mask have no channel axis: written in place, in the caller's mode
+  if ((rc = pad_inputs(g, dtype, p, t, base, &tp, stream))) return rc;
   // accumulate modes: the padded gradient buffers start from the caller's values (like the slices above)
-  if (g.acc_data && (rc = pad_rows(base + p.off_gi, p_x, t.grad_input, w_x, (size_t)g.B * g.DG, stream))) return rc;
+  if (p.pad_c) {
+    if (g.acc_data && (rc = pad_rows(base + p.off_gi, p_x, t.grad_input, w_x, (size_t)g.B * g.DG, stream))) return rc;
+    tp.grad_input = base + p.off_gi;
+  }
   if (g.acc_w && (rc = pad_rows(base + p.off_gw, p_w, t.grad_weight, w_w, (size_t)g.O * g.DG, stream))) return rc;
-  Tensors tp = t;   // grad_offset / grad_mask / grad_bias have no channel axis: written in place, in the caller's mode
-  tp.input = base + p.off_x;
-  tp.weight = base + p.off_w;
-  tp.grad_input = base + p.off_gi;
   tp.grad_weight = base + p.off_gw;
+  if (p.pad_o) {
+    if ((rc = pad_rows(base + p.off_o, p_o, t.grad_output, w_o, g.B, stream))) return rc;   // zero planes for the padding channels
+    tp.grad_output = base + p.off_o;
+    if (g.with_bias) {
+      if (g.acc_w && (rc = pad_rows(base + p.off_gb, (size_t)p.gp.O * es, t.grad_bias, (size_t)g.O * es, 1, stream))) return rc;
+      tp.grad_bias = base + p.off_gb;
+    }
+  }
   if ((rc = native_backward(p.gp, dtype, tp, base + p.off_sub, stream))) return rc;
-  if ((rc = copy_rows(t.grad_input, w_x, base + p.off_gi, p_x, w_x, (size_t)g.B * g.DG, stream))) return rc;
+  if (p.pad_c && (rc = copy_rows(t.grad_input, w_x, base + p.off_gi, p_x, w_x, (size_t)g.B * g.DG, stream))) return rc;
   if ((rc = copy_rows(t.grad_weight, w_w, base + p.off_gw, p_w, w_w, (size_t)g.O * g.DG, stream))) return rc;
+  if (p.pad_o && g.with_bias &&
+      (rc = copy_rows(t.grad_bias, (size_t)g.O * es, base + p.off_gb, (size_t)p.gp.O * es, (size_t)g.O * es, 1, stream)))
+    return rc;
   return record_weight_ready(stream);   // after the copy back
 }
 }  // namespace

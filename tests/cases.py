@@ -75,6 +75,14 @@ CASES = [
     _c("mfma_padc_mdcn3d_c16_o16_dil2", M3, 1, 16, 16, (10, 15, 16), 3, padding=2, dilation=2, tier="medium", seed=86),
     _c("mfma_padc_mdcn3d_c96_o40", M3, 1, 96, 40, (6, 18, 20), 3, tier="medium", seed=87),
     _c("mfma_padc_mdcn2d_c48_o32_9408px", M2, 3, 48, 32, (56, 56), 3, tier="medium", seed=88),
+    # fewer than 16 input or output channels and more than a few hundred pixels: output channels padded to 16, input channels to
+    # 64 (3-D, narrow 2-D) or to a multiple of 8, instead of the shape-generic kernels (round 6, experiment log 23)
+    _c("mfma_padt_mdcn3d_c8_o8_600px", M3, 1, 8, 8, (6, 10, 10), 3, tier="medium", seed=89),
+    _c("mfma_padt_dcn3d_c64_o8_576px", D3, 1, 64, 8, (4, 12, 12), 3, in_step=1, tier="medium", seed=90),
+    _c("mfma_padt_mdcn2d_c32_o8_s2", M2, 2, 32, 8, (35, 33), 3, stride=2, tier="medium", seed=91),
+    _c("mfma_padt_mdcn2d_c20_o12_nobias", M2, 1, 20, 12, (24, 25), 3, bias=False, tier="medium", seed=92),
+    _c("mfma_padt_dcn2d_c8_o5_9408px", D2, 3, 8, 5, (56, 56), 3, tier="medium", seed=93),
+    _c("mfma_padt_dcn3d_c3_o5_k2", D3, 2, 3, 5, (7, 9, 10), 2, padding=0, tier="medium", seed=94),
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),

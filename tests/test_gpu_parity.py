@@ -172,6 +172,10 @@ print("CHUNK_OK")
     ("mfma_pad_dcn2d_dg2_c16_o16", torch.float32, "auto"),
     ("mfma_pad_dcn3d_dg2_c160_o32", torch.float16, "auto"),     # group-padded layout on the native 16-bit kernels (80 -> 128)
     ("mfma_pad_mdcn3d_dg3_c72_o40_dil2", torch.float16, "auto"),
+    ("mfma_padc_dcn3d_c48_o24_s2", torch.float32, "auto"),       # channel-padded plan (one deformable group)
+    ("mfma_padt_dcn3d_c64_o8_576px", torch.float32, "auto"),     # output channels padded to 16: grad_bias through a padded buffer
+    ("mfma_padt_dcn2d_c8_o5_9408px", torch.float32, "auto"),
+    ("mfma_padt_dcn3d_c3_o5_k2", torch.float16, "auto"),
 ])
 def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
     """mdconv_set_accumulate(0): the caller-allocated backward entry points must WRITE every element
