@@ -925,12 +925,14 @@ int split_forward(const Geom &g, int dtype, const SplitFwdPlan &p, const Tensors
 // C' = DG x padded-group channels instead of DG sequences over mostly-padding tiles plus their copies: faster on all 13 shapes
 // measured, 4x growth included (fp32, 4 groups: 64 -> 64 at 56 x 56, B = 16 1.44 -> 1.00 ms; 192 -> 192 at 20 x 20 0.70 -> 0.30;
 // 3-D 64 -> 64 2.41 -> 1.12; profiles/r06_experiments.md 18).  Taken when the padded problem is at most a few times
-// the caller's (kPadMaxGrowthFwd / Bwd); one conv group only (conv groups keep the slices above).
+// the caller's (kPadMaxGrowth); one conv group only (conv groups keep the slices above).
 // ---------------------------------------------------------------------------------------------
 namespace {
-// 16 -> 16 channels in 2 groups (8 -> 32 forward, 8 -> 64 backward): 0.39 ms on the shape-generic kernels, 0.25 padded; groups of 4
-// (8x forward, 16x backward) are faster left alone (16 -> 16 in 4 groups: 0.57 ms generic, 0.60 with a padded forward)
-constexpr int kPadMaxGrowthFwd = 4, kPadMaxGrowthBwd = 8;
+// 16 -> 16 channels in 2 groups (8 -> 32 forward, 8 -> 64 backward): 0.39 ms on the shape-generic kernels, 0.25 padded; in 4 groups
+// (4 -> 32 / 64) at 40 x 40, B = 8: 0.43 ms generic against 0.34 padded, and the generic kernels fall further behind with every output
+// channel (16 -> 256 in 4 groups: 1.76 vs 0.64 ms; 3-D: 5.68 vs 1.27); groups of 2 channels (32x) lose at 16 output channels
+// (profiles/r06_experiments.md 20, 24)
+constexpr int kPadMaxGrowth = 16;
 struct PadPlan {
   Geom gp;            // the padded problem: C = DG x cdp, C_dg = cdp, O = Op
   bool pad_c, pad_o;  // input channels / output channels padded
@@ -993,26 +995,36 @@ bool pad_channels_preferred(const Geom &g) {
   if (g.nd == 3) return g.N >= 2048;
   return g.C >= 32 && g.C < 64 && g.N >= 8192;
 }
-// padded channels of one deformable group for the plan of `g` (0 = no plan)
-static int pad_group_channels(const Geom &g, bool backward) {
+// padded channels of one deformable group for the plan of `g` (0 = no plan).  native_ok: the direction is tiled natively.
+static int pad_group_channels(const Geom &g, bool backward, bool native_ok) {
+  static const int env = getenv("MDCONV_PAD_CHANNELS") ? atoi(getenv("MDCONV_PAD_CHANNELS")) : -1;
   if (g.DG == 1) {
-    if (!pad_channels_preferred(g)) return 0;
-    if (g.C % 64 == 0) return g.C;
-    const bool to_slab = g.nd == 3 || g.C < 16 || (g.C >= 32 && g.C < 64 && g.N >= 8192);
-    return to_slab ? (g.C + 63) / 64 * 64 : (g.C + 7) / 8 * 8;   // (else only C_out is padded: the NCHW kernels need 8 | C_in)
+    if (pad_channels_preferred(g)) {
+      if (g.C % 64 == 0) return g.C;
+      const bool to_slab = g.nd == 3 || g.C < 16 || (g.C >= 32 && g.C < 64 && g.N >= 8192);
+      return to_slab ? (g.C + 63) / 64 * 64 : (g.C + 7) / 8 * 8;   // (else only C_out is padded: the NCHW kernels need 8 | C_in)
+    }
+    // What the kernels do not tile at all -- C_in that is not a multiple of 8 in the backward (100 -> 100 at 40 x 40, B = 8:
+    // 4.85 ms on the shape-generic kernels, 0.27 ms as 104 channels), channel counts below 16 that the size rules above leave
+    // alone: the smallest padded problem, from 512 output pixels (experiment log 24).
+    if (native_ok || env == 0 || g.N < 512) return 0;
+    const int c8 = (g.C + 7) / 8 * 8;
+    return c8 < 16 ? 16 : c8;
   }
-  int cdp;
-  if (backward) cdp = g.Cdg <= 64 ? 64 : (g.Cdg <= 128 ? 128 : (g.Cdg + 255) / 256 * 256);
-  else cdp = (g.Cdg + 2 * kBK - 1) / (2 * kBK) * (2 * kBK);
-  if (cdp == g.Cdg) return 0;
-  if (dg_plan_env() != 1 && cdp > (backward ? kPadMaxGrowthBwd : kPadMaxGrowthFwd) * g.Cdg) return 0;
-  return cdp;
+  if (native_ok) return 0;
+  const int cdp_b = g.Cdg <= 64 ? 64 : (g.Cdg <= 128 ? 128 : (g.Cdg + 255) / 256 * 256);
+  const int cdp_f = (g.Cdg + 2 * kBK - 1) / (2 * kBK) * (2 * kBK);
+  // (the cap looks at the backward's padding in both directions: a padded forward in front of a generic backward is no gain)
+  if (dg_plan_env() != 1 && cdp_b > kPadMaxGrowth * g.Cdg) return 0;
+  return backward ? cdp_b : cdp_f;
 }
 bool pad_plan(const Geom &g, int dtype, bool backward, PadPlan *p) {
   if (g.G != 1 || dg_plan_env() == 2) return false;
-  const int cdp = pad_group_channels(g, backward);
+  const bool native_ok = native_supported(g, dtype, backward);
+  const int cdp = pad_group_channels(g, backward, native_ok);
   if (cdp == 0) return false;
-  const int Op = g.DG == 1 && g.O < 16 ? 16 : g.O;   // (only the one-group plan pads the output channels)
+  // output channels below the kernels' floor of 16: padded too (with several deformable groups from 512 output pixels)
+  const int Op = g.O < 16 && (g.DG == 1 || g.N >= 512) ? 16 : g.O;
   p->pad_c = cdp != g.Cdg;
   p->pad_o = Op != g.O;
   if (!p->pad_c && !p->pad_o) return false;

@@ -83,6 +83,14 @@ CASES = [
     _c("mfma_padt_mdcn2d_c20_o12_nobias", M2, 1, 20, 12, (24, 25), 3, bias=False, tier="medium", seed=92),
     _c("mfma_padt_dcn2d_c8_o5_9408px", D2, 3, 8, 5, (56, 56), 3, tier="medium", seed=93),
     _c("mfma_padt_dcn3d_c3_o5_k2", D3, 2, 3, 5, (7, 9, 10), 2, padding=0, tier="medium", seed=94),
+    # what the fp32 kernels do not tile at all, from 512 output pixels: C_in that is not a multiple of 8 (backward), output channels
+    # below 16 with several deformable groups, deformable groups of 4 channels (16x padding) -- the padded plan instead of the
+    # shape-generic kernels (experiment log 24)
+    _c("mfma_padn_mdcn2d_c100_o40", M2, 2, 100, 40, (18, 17), 3, tier="medium", seed=95),
+    _c("mfma_padn_dcn3d_c20_o24", D3, 1, 20, 24, (6, 10, 10), 3, in_step=1, bias=False, tier="medium", seed=96),
+    _c("mfma_padn_mdcn2d_c128_dg2_o4", M2, 1, 128, 4, (24, 25), 3, dgroups=2, tier="medium", seed=97),
+    _c("mfma_padn_mdcn2d_c16_dg4_o24", M2, 2, 16, 24, (18, 17), 3, dgroups=4, tier="medium", seed=98),
+    _c("mfma_padn_dcn3d_c24_dg2_o8", D3, 1, 24, 8, (6, 10, 10), 3, dgroups=2, tier="medium", seed=99),
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),

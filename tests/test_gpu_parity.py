@@ -176,6 +176,8 @@ print("CHUNK_OK")
     ("mfma_padt_dcn3d_c64_o8_576px", torch.float32, "auto"),     # output channels padded to 16: grad_bias through a padded buffer
     ("mfma_padt_dcn2d_c8_o5_9408px", torch.float32, "auto"),
     ("mfma_padt_dcn3d_c3_o5_k2", torch.float16, "auto"),
+    ("mfma_padn_dcn3d_c20_o24", torch.float32, "auto"),          # backward only padded (C_in not a multiple of 8)
+    ("mfma_padn_dcn3d_c24_dg2_o8", torch.float32, "auto"),       # deformable groups AND output channels padded
 ])
 def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
     """mdconv_set_accumulate(0): the caller-allocated backward entry points must WRITE every element
