@@ -244,8 +244,33 @@ static bool group_padded(const Geom &g, Geom *gv) {
 
 static bool hp_supported_as(const Geom &g, int dtype, bool backward);
 // the geometry the native kernels run for `g`: g itself or its group-padded form
+// One deformable group and 96 / 160 / 192 / 224 padded channels: the pixel-stationary backward gives a pixel a power-of-two lane count,
+// so these widths ran on the tap-stationary kernels at any size; padded to 128 / 256 channels (the same channel map, one "group") they
+// take hp_bwd3 where its size rule applies (fp16 192 -> 192 at 56 x 56, B = 8: 0.91 -> 0.42 ms; 224 -> 256: 1.00 -> 0.44; 3-D 160 -> 160
+// at 8 x 28 x 28: 1.41 -> 1.05; small grids keep the tap-stationary kernels on the unpadded width; experiment log 25)
+static bool width_padded(const Geom &g, Geom *gv) {
+  if (g.cm_pad || g.G != 1 || g.DG != 1 || g.in_cl || !use_col2im2()) return false;
+  const int Cp = (g.C + 31) / 32 * 32;
+  if (Cp <= 64 || Cp >= 256 || pow2_ceil(Cp) == Cp) return false;
+  *gv = g;
+  gv->C = gv->Cg = gv->Cdg = pow2_ceil(Cp);
+  gv->cm_pad = gv->C;
+  gv->cm_real = g.C;
+  gv->C_caller = g.C;
+  return true;
+}
 static bool hp_plan_geom(const Geom &g, int dtype, bool backward, Geom *ge) {
-  if (hp_supported_as(g, dtype, backward)) { *ge = g; return true; }
+  if (hp_supported_as(g, dtype, backward)) {
+    if (backward && width_padded(g, ge) && hp_supported_as(*ge, dtype, true)) {
+      const int bc = chunk_batch(*ge, hp_dims(*ge), true);
+      if (bc > 0) {
+        const Geom gc = chunk_geom(*ge, bc);
+        if (use_bwd3(gc, hp_dims(gc))) return true;
+      }
+    }
+    *ge = g;
+    return true;
+  }
   return group_padded(g, ge) && hp_supported_as(*ge, dtype, backward);
 }
 bool hp_supported(const Geom &g, int dtype, bool backward) {

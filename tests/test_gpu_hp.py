@@ -72,6 +72,11 @@ HP_CASES = [
     _c("hp_mdcn3d_c48_dg2_o32_pad", M3, 1, 48, 32, (4, 5, 6), 3, dgroups=2, bias=False, seed=149),
     _c("hp_dcn3d_c80_dg2_o64_dil2_pad", D3, 1, 80, 64, (4, 6, 5), 3, padding=2, dilation=2, dgroups=2, seed=150),
     _c("hp_mdcn2d_c48_dg4_o64_big_offsets_pad", M2, 3, 48, 64, (8, 7), 3, dgroups=4, seed=151, offset_scale=4.0),
+    # one deformable group, 96 / 160 / 224 padded channels: hp_bwd3 runs them padded to 128 / 256 (hp_host.hip width_padded) where its
+    # size rule applies -- here only in the forced child (tests/test_gpu_hp_forced.py, MDCONV_HP_BWD=4); the tap-stationary kernels by default
+    _c("hp_mdcn2d_c96_o64_wpad", M2, 2, 96, 64, (9, 10), 3, seed=152),
+    _c("hp_dcn3d_c160_o48_wpad", D3, 1, 160, 48, (4, 5, 6), 3, bias=False, seed=153),
+    _c("hp_mdcn2d_c200_o40_s2_wpad", M2, 2, 200, 40, (12, 11), 3, stride=2, seed=154),
 ]
 
 CASE_BY_HP = {c["name"]: c for c in HP_CASES}
@@ -252,8 +257,9 @@ def test_backward_kernel_choice_follows_shape_and_size():
     # 16 k-steps in 3-D, 256 channels: hp_bwd2 (spilling instance) up to ~36 tiles, hp_bwd3 beyond (experiment log 16)
     few3 = _c("hp_choice_mdcn3d_c256_o256_b2", M3, 2, 256, 256, (4, 14, 14), 3, seed=162)       # 13 tiles x 27 taps
     many3 = _c("hp_choice_mdcn3d_c256_o256_b8", M3, 8, 256, 256, (4, 14, 14), 3, seed=163)      # 49 tiles
+    wpad = _c("hp_choice_mdcn2d_c96_o32_b12_56", M2, 12, 96, 32, (56, 56), 3, seed=164)        # 96 channels run as 128: 294 tiles
     for case, want in ((big, "hp_bwd3_kernel"), (wide, "hp_bwd3_kernel"), (by["hp_mdcn2d_c64_dg4_o64"], "hp_bwd3_kernel"),
-                       (few3, "hp_bwd2_kernel"), (many3, "hp_bwd3_kernel"),
+                       (few3, "hp_bwd2_kernel"), (many3, "hp_bwd3_kernel"), (wpad, "hp_bwd3_kernel"),
                        (by["hp_mdcn3d_c128_o128_dil2"], "hp_bwd2_kernel"), (by["hp_mdcn2d_c64_o256"], "hp_bwd2_kernel"),
                        (by["hp_mdcn2d_c256_o256_g32_dg4"], "hp_bwd2_kernel"), (by["hp_mdcn2d_c256_o64_dg8"], "hp_bwd_kernel")):
         t = make_inputs(case, dtype=torch.float16, device="cuda")
