@@ -29,8 +29,14 @@ def main():
     dtype = DT["f16" if "f16" in sys.argv else "f32"]
     op = M3 if nd == 3 else M2
     sz, B = ((8, 20, 20), 2) if nd == 3 else ((40, 40), 8)
+    if "small" in sys.argv:
+        sz, B = ((4, 7, 7), 4) if nd == 3 else ((14, 14), 8)
+    if "large" in sys.argv:
+        sz, B = ((8, 40, 40), 2) if nd == 3 else ((112, 112), 4)
     chans = [3, 8, 16, 24, 40, 64, 72, 100, 128, 136, 200, 256, 264, 320, 512]
     outs = [4, 16, 40, 64, 100, 256]
+    if "large" in sys.argv:
+        chans, outs = [8, 16, 24, 40, 64, 72, 100, 128, 200, 256], [4, 16, 64, 100, 256]
     cache = {}
 
     def t_of(C, O, G, DG):
