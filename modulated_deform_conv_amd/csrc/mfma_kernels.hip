@@ -934,8 +934,11 @@ namespace {
 // (profiles/r06_experiments.md 20, 24)
 constexpr int kPadMaxGrowth = 16;
 struct PadPlan {
-  Geom gp;            // the padded problem: C = DG x cdp, C_dg = cdp, O = Op
+  Geom gp;            // the padded problem
   bool pad_c, pad_o;  // input channels / output channels padded
+  // channel groups of the input (conv groups, else deformable groups): count, channels each (caller's / padded);
+  // output groups (conv groups): count, channels each; weight sub-rows per output channel ([O][DG][C_dg][K] with one conv group)
+  int ng, cin, cinp, nog, og, ogp, wsub;
   size_t off_x, off_w, off_gi, off_gw, off_o, off_b, off_gb, off_sub, total;   // off_o: output (forward) / grad_output (backward)
 };
 // dst[r][0 .. dwidth) = src[r][0 .. width) followed by zeros (element = W)
@@ -962,6 +965,61 @@ int pad_rows(void *dst, size_t dwidth, const void *src, size_t width, size_t row
                        (int64_t)(dwidth / 2), (const unsigned short *)src, (int64_t)(width / 2), (int64_t)rows);
   return check_launch("pad_rows");
 }
+// Rows in groups of `inner` (padded: `inner_p`), `outer` groups: dst row (q, r) = src row (q, r) widened to dwidth with zeros for
+// r < inner, a zero row for inner <= r < inner_p (weights: the rows of one conv group's output channels, padded to the kernels' floor)
+template <typename W>
+__global__ __launch_bounds__(256) void pad_rows_grouped_kernel(W *__restrict__ dst, int64_t dwidth, const W *__restrict__ src,
+                                                               int64_t width, int64_t inner, int64_t inner_p, int64_t outer) {
+  const int64_t n = dwidth * inner_p * outer;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t rd = i / dwidth, c = i - rd * dwidth;
+    const int64_t q = rd / inner_p, r = rd - q * inner_p;
+    dst[i] = (r < inner && c < width) ? src[(q * inner + r) * width + c] : (W)0;
+  }
+}
+// the inverse: dst row (q, r) (width elements) = the first `width` elements of src row (q, r) of the padded layout
+template <typename W>
+__global__ __launch_bounds__(256) void unpad_rows_grouped_kernel(W *__restrict__ dst, int64_t width, const W *__restrict__ src,
+                                                                 int64_t swidth, int64_t inner, int64_t inner_p, int64_t outer) {
+  const int64_t n = width * inner * outer;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t rs = i / width, c = i - rs * width;
+    const int64_t q = rs / inner, r = rs - q * inner;
+    dst[i] = src[(q * inner_p + r) * swidth + c];
+  }
+}
+int pad_rows_grouped(void *dst, size_t dwidth, const void *src, size_t width, size_t inner, size_t inner_p, size_t outer,
+                     hipStream_t stream) {
+  const bool words = ((dwidth | width) & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 3) == 0;
+  const size_t es = words ? 4 : 2;
+  const int64_t n = (int64_t)(dwidth / es) * (int64_t)(inner_p * outer);
+  const int64_t blocks = (n + 255) / 256;
+  const dim3 grid((unsigned)(blocks > 16384 ? 16384 : (blocks < 1 ? 1 : blocks)));
+  if (words)
+    hipLaunchKernelGGL(pad_rows_grouped_kernel<unsigned>, grid, dim3(256), 0, stream, (unsigned *)dst, (int64_t)(dwidth / 4),
+                       (const unsigned *)src, (int64_t)(width / 4), (int64_t)inner, (int64_t)inner_p, (int64_t)outer);
+  else
+    hipLaunchKernelGGL(pad_rows_grouped_kernel<unsigned short>, grid, dim3(256), 0, stream, (unsigned short *)dst,
+                       (int64_t)(dwidth / 2), (const unsigned short *)src, (int64_t)(width / 2), (int64_t)inner, (int64_t)inner_p,
+                       (int64_t)outer);
+  return check_launch("pad_rows_grouped");
+}
+int unpad_rows_grouped(void *dst, size_t width, const void *src, size_t swidth, size_t inner, size_t inner_p, size_t outer,
+                       hipStream_t stream) {
+  const bool words = ((swidth | width) & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 3) == 0;
+  const size_t es = words ? 4 : 2;
+  const int64_t n = (int64_t)(width / es) * (int64_t)(inner * outer);
+  const int64_t blocks = (n + 255) / 256;
+  const dim3 grid((unsigned)(blocks > 16384 ? 16384 : (blocks < 1 ? 1 : blocks)));
+  if (words)
+    hipLaunchKernelGGL(unpad_rows_grouped_kernel<unsigned>, grid, dim3(256), 0, stream, (unsigned *)dst, (int64_t)(width / 4),
+                       (const unsigned *)src, (int64_t)(swidth / 4), (int64_t)inner, (int64_t)inner_p, (int64_t)outer);
+  else
+    hipLaunchKernelGGL(unpad_rows_grouped_kernel<unsigned short>, grid, dim3(256), 0, stream, (unsigned short *)dst,
+                       (int64_t)(width / 2), (const unsigned short *)src, (int64_t)(swidth / 2), (int64_t)inner, (int64_t)inner_p,
+                       (int64_t)outer);
+  return check_launch("unpad_rows_grouped");
+}
 // MDCONV_DG_PLAN = pad | split forces one plan where both exist (developer A/B; default: by growth)
 int dg_plan_env() {
   static const int v = [] {
@@ -986,7 +1044,10 @@ int dg_plan_env() {
 // MDCONV_PAD_CHANNELS = 0 | 1: never / wherever eligible (the test suite's way to reach the plan with small shapes).
 bool pad_channels_preferred(const Geom &g) {
   static const int env = getenv("MDCONV_PAD_CHANNELS") ? atoi(getenv("MDCONV_PAD_CHANNELS")) : -1;
-  if (env == 0 || g.G != 1 || g.DG != 1) return false;
+  if (env == 0 || g.DG != 1) return false;
+  if (g.G != 1)   // conv groups: the 3-D slab rule per group (3-D 200 -> 64 in 2 groups at 8 x 20 x 20: 1.19 ms, 256 -> 64: 0.61)
+    // (at most 2x: 64 -> 128 in 4 groups of 16 -> 64 at 8 x 14 x 14 lost 26 %)
+    return g.nd == 3 && g.Cg >= 32 && g.Cg % 64 != 0 && (env > 0 || g.N >= 2048);
   const bool tiny_c = g.C < 16, tiny_o = g.O < 16;
   if (!tiny_c && !tiny_o && g.C % 64 == 0) return false;
   if (env > 0) return true;
@@ -1019,51 +1080,67 @@ static int pad_group_channels(const Geom &g, bool backward, bool native_ok) {
   return backward ? cdp_b : cdp_f;
 }
 bool pad_plan(const Geom &g, int dtype, bool backward, PadPlan *p) {
-  if (g.G != 1 || dg_plan_env() == 2) return false;
+  if (dg_plan_env() == 2) return false;
   const bool native_ok = native_supported(g, dtype, backward);
-  const int cdp = pad_group_channels(g, backward, native_ok);
-  if (cdp == 0) return false;
-  // output channels below the kernels' floor of 16: padded too (with several deformable groups from 512 output pixels)
-  const int Op = g.O < 16 && (g.DG == 1 || g.N >= 512) ? 16 : g.O;
-  p->pad_c = cdp != g.Cdg;
-  p->pad_o = Op != g.O;
-  if (!p->pad_c && !p->pad_o) return false;
   Geom gp = g;
-  gp.C = gp.Cg = g.DG * cdp;
-  gp.Cdg = cdp;
-  gp.O = gp.Og = Op;
+  if (g.G == 1) {
+    const int cdp = pad_group_channels(g, backward, native_ok);
+    if (cdp == 0) return false;
+    // output channels below the kernels' floor of 16: padded too (with several deformable groups from 512 output pixels)
+    const int Op = g.O < 16 && (g.DG == 1 || g.N >= 512) ? 16 : g.O;
+    p->ng = g.DG; p->cin = g.Cdg; p->cinp = cdp;
+    p->nog = 1; p->og = g.O; p->ogp = Op;
+    p->wsub = g.DG;
+    gp.C = gp.Cg = g.DG * cdp;
+    gp.Cdg = cdp;
+    gp.O = gp.Og = Op;
+  } else {
+    // conv groups (one deformable group): per-group channel counts the kernels do not tile -- C_in / G not a multiple of 8 or
+    // below 16, fewer than 16 output channels per group -- padded PER CONV GROUP, from 512 output pixels (experiment log 28)
+    static const int env = getenv("MDCONV_PAD_CHANNELS") ? atoi(getenv("MDCONV_PAD_CHANNELS")) : -1;
+    const bool slab = pad_channels_preferred(g);   // 3-D: whole 64-channel slabs per group for the channels-last kernels
+    if (g.DG != 1 || env == 0 || (!slab && (native_ok || g.N < 512))) return false;
+    const int c8 = (g.Cg + 7) / 8 * 8;
+    p->ng = g.G; p->cin = g.Cg; p->cinp = slab ? (g.Cg + 63) / 64 * 64 : (c8 < 16 ? 16 : c8);
+    p->nog = g.G; p->og = g.Og; p->ogp = g.Og < 16 ? 16 : g.Og;
+    p->wsub = 1;
+    gp.Cg = p->cinp;
+    gp.C = gp.Cdg = g.G * p->cinp;
+    gp.Og = p->ogp;
+    gp.O = g.G * p->ogp;
+  }
+  p->pad_c = p->cinp != p->cin;
+  p->pad_o = p->ogp != p->og;
+  if (!p->pad_c && !p->pad_o) return false;
   if (!native_supported(gp, dtype, backward)) return false;
   p->gp = gp;
   const size_t es = dtype == MDCONV_F32 ? 4 : 2;
   size_t off = 0;
   auto take = [&](size_t &slot, size_t elems) { slot = off; off += align_up(elems * es); };
   take(p->off_x, p->pad_c ? (size_t)g.B * gp.C * g.S_i : 0);
-  take(p->off_w, (size_t)Op * gp.C * g.K);
+  take(p->off_w, (size_t)gp.O * gp.Cg * g.K);
   take(p->off_gi, backward && p->pad_c ? (size_t)g.B * gp.C * g.S_i : 0);
-  take(p->off_gw, backward ? (size_t)Op * gp.C * g.K : 0);
-  take(p->off_o, p->pad_o ? (size_t)g.B * Op * g.S_o : 0);
-  take(p->off_b, p->pad_o && g.with_bias && !backward ? (size_t)Op : 0);
-  take(p->off_gb, p->pad_o && g.with_bias && backward ? (size_t)Op : 0);
+  take(p->off_gw, backward ? (size_t)gp.O * gp.Cg * g.K : 0);
+  take(p->off_o, p->pad_o ? (size_t)g.B * gp.O * g.S_o : 0);
+  take(p->off_b, p->pad_o && g.with_bias && !backward ? (size_t)gp.O : 0);
+  take(p->off_gb, p->pad_o && g.with_bias && backward ? (size_t)gp.O : 0);
   p->off_sub = off;
   p->total = off + native_workspace_bytes(gp, dtype, backward);
   return true;
 }
-// input [B][DG][C_dg][S_i] -> [B][DG][cdp][S_i], weight [O][DG][C_dg][K] -> [Op][DG][cdp][K] (rows O .. Op - 1 zero): rows of one
-// (image | output channel, group), contiguous on both sides
+// input [B][groups][cin][S_i] -> [B][groups][cinp][S_i]; weight [groups_o][og][wsub][cin][K] -> [groups_o][ogp][wsub][cinp][K] (the
+// rows og .. ogp - 1 of every output group zero): rows of one (image | output channel, group), contiguous on both sides
 int pad_inputs(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, char *base, Tensors *tp, hipStream_t stream) {
   const size_t es = dtype == MDCONV_F32 ? 4 : 2;
   int rc;
   if (p.pad_c) {
-    if ((rc = pad_rows(base + p.off_x, (size_t)p.gp.Cdg * g.S_i * es, t.input, (size_t)g.Cdg * g.S_i * es, (size_t)g.B * g.DG, stream)))
+    if ((rc = pad_rows(base + p.off_x, (size_t)p.cinp * g.S_i * es, t.input, (size_t)p.cin * g.S_i * es, (size_t)g.B * p.ng, stream)))
       return rc;
     tp->input = base + p.off_x;
   }
-  if ((rc = pad_rows(base + p.off_w, (size_t)p.gp.Cdg * g.K * es, t.weight, (size_t)g.Cdg * g.K * es, (size_t)g.O * g.DG, stream)))
+  if ((rc = pad_rows_grouped(base + p.off_w, (size_t)p.cinp * g.K * es, t.weight, (size_t)p.cin * g.K * es, (size_t)p.og * p.wsub,
+                             (size_t)p.ogp * p.wsub, p.nog, stream)))
     return rc;
-  if (p.pad_o) {
-    const size_t row = (size_t)p.gp.C * g.K * es;
-    if ((rc = pad_rows(base + p.off_w + (size_t)g.O * row, (size_t)(p.gp.O - g.O) * row, t.weight, 0, 1, stream))) return rc;
-  }
   tp->weight = base + p.off_w;
   return MDCONV_OK;
 }
@@ -1073,47 +1150,48 @@ int pad_forward(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, vo
   int rc;
   Tensors tp = t;
   if ((rc = pad_inputs(g, dtype, p, t, base, &tp, stream))) return rc;
-  if (p.pad_o) {   // the kernels write Op output channels (and read Op bias values): a workspace tile, the real rows copied out
+  if (p.pad_o) {   // the kernels write ogp output channels per group (and read as many bias values): a workspace tile, real rows copied out
     if (g.with_bias) {
-      if ((rc = pad_rows(base + p.off_b, (size_t)p.gp.O * es, t.bias, (size_t)g.O * es, 1, stream))) return rc;
+      if ((rc = pad_rows(base + p.off_b, (size_t)p.ogp * es, t.bias, (size_t)p.og * es, p.nog, stream))) return rc;
       tp.bias = base + p.off_b;
     }
     tp.output = base + p.off_o;
   }
   if ((rc = native_forward(p.gp, dtype, tp, base + p.off_sub, stream))) return rc;
   if (!p.pad_o) return MDCONV_OK;
-  const size_t w_o = (size_t)g.O * g.S_o * es;
-  return copy_rows(t.output, w_o, base + p.off_o, (size_t)p.gp.O * g.S_o * es, w_o, g.B, stream);
+  const size_t w_o = (size_t)p.og * g.S_o * es;
+  return copy_rows(t.output, w_o, base + p.off_o, (size_t)p.ogp * g.S_o * es, w_o, (size_t)g.B * p.nog, stream);
 }
 int pad_backward(const Geom &g, int dtype, const PadPlan &p, const Tensors &t, void *ws, hipStream_t stream) {
   char *base = (char *)ws;
   const size_t es = dtype == MDCONV_F32 ? 4 : 2;
-  const size_t w_x = (size_t)g.Cdg * g.S_i * es, p_x = (size_t)p.gp.Cdg * g.S_i * es;
-  const size_t w_w = (size_t)g.Cdg * g.K * es, p_w = (size_t)p.gp.Cdg * g.K * es;
-  const size_t w_o = (size_t)g.O * g.S_o * es, p_o = (size_t)p.gp.O * g.S_o * es;
+  const size_t w_x = (size_t)p.cin * g.S_i * es, p_x = (size_t)p.cinp * g.S_i * es;
+  const size_t w_w = (size_t)p.cin * g.K * es, p_w = (size_t)p.cinp * g.K * es;
+  const size_t w_o = (size_t)p.og * g.S_o * es, p_o = (size_t)p.ogp * g.S_o * es;
+  const size_t wi = (size_t)p.og * p.wsub, wip = (size_t)p.ogp * p.wsub;   // weight rows of one output group (caller's / padded)
   int rc;
   Tensors tp = t;   // grad_offset / grad_mask have no channel axis: written in place, in the caller's mode
   if ((rc = pad_inputs(g, dtype, p, t, base, &tp, stream))) return rc;
   // accumulate modes: the padded gradient buffers start from the caller's values (like the slices above)
   if (p.pad_c) {
-    if (g.acc_data && (rc = pad_rows(base + p.off_gi, p_x, t.grad_input, w_x, (size_t)g.B * g.DG, stream))) return rc;
+    if (g.acc_data && (rc = pad_rows(base + p.off_gi, p_x, t.grad_input, w_x, (size_t)g.B * p.ng, stream))) return rc;
     tp.grad_input = base + p.off_gi;
   }
-  if (g.acc_w && (rc = pad_rows(base + p.off_gw, p_w, t.grad_weight, w_w, (size_t)g.O * g.DG, stream))) return rc;
+  if (g.acc_w && (rc = pad_rows_grouped(base + p.off_gw, p_w, t.grad_weight, w_w, wi, wip, p.nog, stream))) return rc;
   tp.grad_weight = base + p.off_gw;
   if (p.pad_o) {
-    if ((rc = pad_rows(base + p.off_o, p_o, t.grad_output, w_o, g.B, stream))) return rc;   // zero planes for the padding channels
+    if ((rc = pad_rows(base + p.off_o, p_o, t.grad_output, w_o, (size_t)g.B * p.nog, stream))) return rc;   // zero planes for the padding channels
     tp.grad_output = base + p.off_o;
     if (g.with_bias) {
-      if (g.acc_w && (rc = pad_rows(base + p.off_gb, (size_t)p.gp.O * es, t.grad_bias, (size_t)g.O * es, 1, stream))) return rc;
+      if (g.acc_w && (rc = pad_rows(base + p.off_gb, (size_t)p.ogp * es, t.grad_bias, (size_t)p.og * es, p.nog, stream))) return rc;
       tp.grad_bias = base + p.off_gb;
     }
   }
   if ((rc = native_backward(p.gp, dtype, tp, base + p.off_sub, stream))) return rc;
-  if (p.pad_c && (rc = copy_rows(t.grad_input, w_x, base + p.off_gi, p_x, w_x, (size_t)g.B * g.DG, stream))) return rc;
-  if ((rc = copy_rows(t.grad_weight, w_w, base + p.off_gw, p_w, w_w, (size_t)g.O * g.DG, stream))) return rc;
+  if (p.pad_c && (rc = copy_rows(t.grad_input, w_x, base + p.off_gi, p_x, w_x, (size_t)g.B * p.ng, stream))) return rc;
+  if ((rc = unpad_rows_grouped(t.grad_weight, w_w, base + p.off_gw, p_w, wi, wip, p.nog, stream))) return rc;
   if (p.pad_o && g.with_bias &&
-      (rc = copy_rows(t.grad_bias, (size_t)g.O * es, base + p.off_gb, (size_t)p.gp.O * es, (size_t)g.O * es, 1, stream)))
+      (rc = copy_rows(t.grad_bias, (size_t)p.og * es, base + p.off_gb, (size_t)p.ogp * es, (size_t)p.og * es, p.nog, stream)))
     return rc;
   return record_weight_ready(stream);   // after the copy back
 }

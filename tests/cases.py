@@ -91,6 +91,14 @@ CASES = [
     _c("mfma_padn_mdcn2d_c128_dg2_o4", M2, 1, 128, 4, (24, 25), 3, dgroups=2, tier="medium", seed=97),
     _c("mfma_padn_mdcn2d_c16_dg4_o24", M2, 2, 16, 24, (18, 17), 3, dgroups=4, tier="medium", seed=98),
     _c("mfma_padn_dcn3d_c24_dg2_o8", D3, 1, 24, 8, (6, 10, 10), 3, dgroups=2, tier="medium", seed=99),
+    # conv groups whose per-group channel counts the fp32 kernels do not tile (C_in / G not a multiple of 8 or below 16, fewer than
+    # 16 output channels per group): padded per conv group (experiment log 28)
+    _c("mfma_padg_mdcn2d_g2_c100_o40", M2, 2, 100, 40, (18, 17), 3, groups=2, tier="medium", seed=100),
+    _c("mfma_padg_dcn3d_g4_c32_o8", D3, 1, 32, 8, (6, 10, 10), 3, groups=4, in_step=1, tier="medium", seed=101),
+    _c("mfma_padg_mdcn2d_g2_c64_o8_nobias", M2, 1, 64, 8, (24, 25), 3, groups=2, bias=False, tier="medium", seed=102),
+    _c("mfma_padg_dcn2d_g3_c36_o36_s2", D2, 2, 36, 36, (35, 33), 3, stride=2, groups=3, tier="medium", seed=103),
+    _c("mfma_padg_mdcn3d_g2_c24_o40_k2", M3, 2, 24, 40, (7, 9, 10), 2, padding=0, groups=2, tier="medium", seed=104),
+    _c("mfma_padg_dcn3d_g2_c80_o32_2304px", D3, 2, 80, 32, (8, 12, 12), 3, groups=2, tier="medium", seed=105),   # 40 -> 64 per group: slab rule
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),

@@ -178,6 +178,9 @@ print("CHUNK_OK")
     ("mfma_padt_dcn3d_c3_o5_k2", torch.float16, "auto"),
     ("mfma_padn_dcn3d_c20_o24", torch.float32, "auto"),          # backward only padded (C_in not a multiple of 8)
     ("mfma_padn_dcn3d_c24_dg2_o8", torch.float32, "auto"),       # deformable groups AND output channels padded
+    ("mfma_padg_dcn3d_g4_c32_o8", torch.float32, "auto"),        # conv groups: input and output channels padded per group
+    ("mfma_padg_dcn2d_g3_c36_o36_s2", torch.float32, "auto"),
+    ("mfma_padg_dcn2d_g3_c36_o36_s2", torch.float16, "auto"),
 ])
 def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
     """mdconv_set_accumulate(0): the caller-allocated backward entry points must WRITE every element
