@@ -1098,14 +1098,37 @@ bool pad_plan(const Geom &g, int dtype, bool backward, PadPlan *p) {
     // conv groups (one deformable group): per-group channel counts the kernels do not tile -- C_in / G not a multiple of 8 or
     // below 16, fewer than 16 output channels per group -- padded PER CONV GROUP, from 512 output pixels (experiment log 28)
     static const int env = getenv("MDCONV_PAD_CHANNELS") ? atoi(getenv("MDCONV_PAD_CHANNELS")) : -1;
-    const bool slab = pad_channels_preferred(g);   // 3-D: whole 64-channel slabs per group for the channels-last kernels
-    if (g.DG != 1 || env == 0 || (!slab && (native_ok || g.N < 512))) return false;
-    const int c8 = (g.Cg + 7) / 8 * 8;
-    p->ng = g.G; p->cin = g.Cg; p->cinp = slab ? (g.Cg + 63) / 64 * 64 : (c8 < 16 ? 16 : c8);
     p->nog = g.G; p->og = g.Og; p->ogp = g.Og < 16 ? 16 : g.Og;
-    p->wsub = 1;
-    gp.Cg = p->cinp;
-    gp.C = gp.Cdg = g.G * p->cinp;
+    if (g.DG == 1) {
+      const bool slab = pad_channels_preferred(g);   // 3-D: whole 64-channel slabs per group for the channels-last kernels
+      if (env == 0 || (!slab && (native_ok || g.N < 512))) return false;
+      const int c8 = (g.Cg + 7) / 8 * 8;
+      p->ng = g.G; p->cin = g.Cg; p->cinp = slab ? (g.Cg + 63) / 64 * 64 : (c8 < 16 ? 16 : c8);
+      p->wsub = 1;
+      gp.Cg = p->cinp;
+      gp.C = gp.Cdg = g.G * p->cinp;
+    } else {
+      // conv groups AND deformable groups the kernels do not tile, NESTED (one grouping refines the other, so that padding the
+      // finer groups by the same amount keeps every channel in its conv group and its deformable group): the deformable group
+      // goes to the next size the kernels tile that the finer groups divide (experiment log 29)
+      if (native_ok || env == 0 || g.N < 512) return false;
+      const int u = g.Cg < g.Cdg ? g.Cg : g.Cdg;   // the finer group
+      if (g.Cg % u || g.Cdg % u) return false;
+      const int m = g.Cdg / u;                      // finer groups per deformable group
+      int cdp = 0;
+      if (backward) {
+        for (int cand : {64, 128, 256, 512, 768, 1024})
+          if (cand >= g.Cdg && cand % m == 0) { cdp = cand; break; }
+      } else {
+        cdp = (g.Cdg + 2 * kBK * m - 1) / (2 * kBK * m) * (2 * kBK * m);   // finer groups of whole 32-channel stages
+      }
+      if (cdp == 0 || cdp > kPadMaxGrowth * g.Cdg) return false;
+      p->ng = g.C / u; p->cin = u; p->cinp = cdp / m;
+      p->wsub = g.Cg / u;
+      gp.Cg = p->wsub * p->cinp;
+      gp.Cdg = cdp;
+      gp.C = p->ng * p->cinp;
+    }
     gp.Og = p->ogp;
     gp.O = g.G * p->ogp;
   }

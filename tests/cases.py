@@ -99,6 +99,12 @@ CASES = [
     _c("mfma_padg_dcn2d_g3_c36_o36_s2", D2, 2, 36, 36, (35, 33), 3, stride=2, groups=3, tier="medium", seed=103),
     _c("mfma_padg_mdcn3d_g2_c24_o40_k2", M3, 2, 24, 40, (7, 9, 10), 2, padding=0, groups=2, tier="medium", seed=104),
     _c("mfma_padg_dcn3d_g2_c80_o32_2304px", D3, 2, 80, 32, (8, 12, 12), 3, groups=2, tier="medium", seed=105),   # 40 -> 64 per group: slab rule
+    # conv groups AND deformable groups, nested: equal (4 x 4 groups of 25), deformable groups finer (2 conv x 4 deformable of 12),
+    # conv groups finer (4 conv x 2 deformable: 20 per conv group, 40 per deformable group), 3-D with few outputs per group
+    _c("mfma_padgd_mdcn2d_g4_dg4_c100_o40", M2, 2, 100, 40, (18, 17), 3, groups=4, dgroups=4, tier="medium", seed=106),
+    _c("mfma_padgd_dcn2d_g2_dg4_c48_o32", D2, 2, 48, 32, (18, 17), 3, groups=2, dgroups=4, in_step=1, tier="medium", seed=107),
+    _c("mfma_padgd_mdcn2d_g4_dg2_c80_o64_nobias", M2, 1, 80, 64, (24, 25), 3, groups=4, dgroups=2, bias=False, tier="medium", seed=108),
+    _c("mfma_padgd_dcn3d_g2_dg2_c40_o8", D3, 1, 40, 8, (6, 10, 10), 3, groups=2, dgroups=2, tier="medium", seed=109),
     # more than 64 KB of dynamic LDS in GEMM-1 (C_out = 512) and several channel passes (C_in = 512)
     _c("mfma_mdcn2d_c256_o512_6x6", M2, 1, 256, 512, (6, 6), 3, bias=False, tier="medium", seed=37),
     _c("mfma_dcn2d_c512_o32_7x5", D2, 2, 512, 32, (7, 5), 3, tier="medium", seed=38),

@@ -181,6 +181,8 @@ print("CHUNK_OK")
     ("mfma_padg_dcn3d_g4_c32_o8", torch.float32, "auto"),        # conv groups: input and output channels padded per group
     ("mfma_padg_dcn2d_g3_c36_o36_s2", torch.float32, "auto"),
     ("mfma_padg_dcn2d_g3_c36_o36_s2", torch.float16, "auto"),
+    ("mfma_padgd_dcn2d_g2_dg4_c48_o32", torch.float32, "auto"),   # conv groups and deformable groups padded together
+    ("mfma_padgd_dcn3d_g2_dg2_c40_o8", torch.float32, "auto"),
 ])
 def test_overwrite_mode_writes_every_gradient_element(name, dtype, path):
     """mdconv_set_accumulate(0): the caller-allocated backward entry points must WRITE every element
