@@ -228,6 +228,16 @@ def test_workspace_plan_and_layout_query_without_gpu(capi):
     # the same in fp32: ONE padded problem (groups of 64 in the backward = 256 channels): copies of input / weight + their gradients
     f32pad = _plan_desc(capi, 2, capi.F32, 2, 96, 64, (8, 8), DG=4)
     assert ws(f32pad, 1) >= (2 * 2 * 256 * 64 + 2 * 64 * 256 * 9) * 4
+    # padded plans of the fp32 kernels (host planning): output channels below 16 -> a 16-channel grad_output copy; C_in not a multiple
+    # of 8 -> padded input / grad_input copies in the backward only; conv groups with 50 channels per group -> 56 per group
+    o8 = _plan_desc(capi, 3, capi.F32, 1, 64, 8, (4, 12, 12))
+    assert ws(o8, 1) >= (1 * 16 * 576 + 2 * 16 * 64 * 27) * 4 and ws(o8, 0) >= (1 * 16 * 576 + 16 * 64 * 27) * 4
+    c100 = _plan_desc(capi, 2, capi.F32, 2, 100, 40, (18, 17))
+    assert ws(c100, 1) >= 2 * 2 * 104 * 18 * 17 * 4
+    g2 = _plan_desc(capi, 2, capi.F32, 2, 100, 40, (18, 17), G=2)
+    assert ws(g2, 1) >= 2 * 2 * 112 * 18 * 17 * 4
+    tiny = _plan_desc(capi, 2, capi.F32, 1, 4, 4, (8, 8))                      # BASELINE configs[0]: shape-generic kernels, no workspace
+    assert ws(tiny, 0) == 0 and ws(tiny, 1) == 0
     assert L.mdconv_input_layout_supported(ctypes.byref(cfg5), 0, 1) == 1    # NCHW always
     assert L.mdconv_input_layout_supported(ctypes.byref(cfg5), 7, 1) == 0
     assert capi.lib().mdconv_profile_name(9) == b""
